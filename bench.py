@@ -1,0 +1,176 @@
+#!/usr/bin/env python3
+"""bench.py -- MaxSim rerank throughput on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N --steps K --warmup W]          (N > 1: launched by torch.distributed.run)
+
+Workload (config.workload): BASELINE.json configs[1] -- a step is one batch of 256 queries x 1000 candidate docs,
+32 x 180 tokens, dim 128, fp32 token index resident in HBM, fused gather+MaxSim+top-100.  The synthetic index is
+1,000,000 docs (92 GB >> 256 MB Infinity Cache) and every step draws fresh random candidates, so document reads
+are real HBM reads.  N > 1 (doc-sharded, weak scaling): each rank holds its own 1M-doc shard, the batch is
+256*N queries, each query's 1000 candidates are stratified 1000/N per shard, local top-100 -> one RCCL
+all_gather -> per-query merge.  value = queries of all ranks / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+import torch.nn.functional as F
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+LQ, LD, H, NQ, NCAND, TOPK = 32, 180, 128, 256, 1000, 100
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+
+def build_index(ndocs, dev, seed, dtype):
+    """F.normalize(randn) token embeddings, generated on-device in chunks (encoder output contract, BaseModel.py:26)."""
+    gen = torch.Generator(device=dev).manual_seed(seed)
+    idx = torch.empty(ndocs * LD, H, dtype=dtype, device=dev)
+    chunk = 8192 * LD
+    for s in range(0, ndocs * LD, chunk):
+        e = min(s + chunk, ndocs * LD)
+        idx[s:e] = F.normalize(torch.randn(e - s, H, generator=gen, device=dev), dim=-1).to(dtype)
+    return idx
+
+
+def cpu_baseline(seconds=12.0):
+    """The oracle restatement of the reference's score() (BaseModel.py:39-46) on the host cores: the reference's
+    unit of work, 1 query x 1000 docs per call (colbert_ranker.py:111-112), fp32."""
+    from oracle.maxsim_oracle import ref_score
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    gen = torch.Generator().manual_seed(0)
+    Q = F.normalize(torch.randn(1, LQ, H, generator=gen), dim=-1)
+    D = F.normalize(torch.randn(NCAND, LD, H, generator=gen), dim=-1)
+    qm, dm = torch.ones(1, LQ, dtype=torch.long), torch.ones(NCAND, LD, dtype=torch.long)
+    for _ in range(2):
+        ref_score(Q, D, qm, dm)
+    n, t0 = 0, time.perf_counter()
+    while True:
+        ref_score(Q, D, qm, dm)
+        n += 1
+        el = time.perf_counter() - t0
+        if (el >= seconds and n >= 10) or el >= 3 * seconds:
+            break
+    return {"value": round(n / el, 3), "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": f"{n} calls of 1 query x {NCAND} docs x ({LQ}x{LD}) tokens dim {H} fp32, torch CPU, {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--ndocs", type=int, default=1_000_000, help="docs per GPU shard")
+    ap.add_argument("--index-dtype", default="fp32", choices=["fp32", "fp16", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import colbert_amd
+    from colbert_amd.sharded import ShardedRanker
+
+    dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.index_dtype]
+    esize = torch.empty(0, dtype=dtype).element_size()
+    ndocs = args.ndocs
+    idx = build_index(ndocs, dev, 1234 + rank, dtype)
+    ranker = colbert_amd.ColbertRanker.__new__(colbert_amd.ColbertRanker)
+    # uniform 180-token docs: strides = [180], one bucket, no padding floor
+    ranker.maxsim_dtype = torch.float32
+    ranker.device = dev
+    ranker.model = None
+    ranker.pid_offset = rank * ndocs
+    ranker.tensor = idx
+    ranker.num_embeddings = ndocs * LD
+    ranker.init_ranker([LD] * ndocs)
+    lo, hi = rank * ndocs, (rank + 1) * ndocs
+    sharded = ShardedRanker(ranker, lo, hi)
+
+    nq = NQ * world
+    per = NCAND // world
+    assert per * world == NCAND
+    total = args.warmup + args.steps
+    gq = torch.Generator(device=dev).manual_seed(1)            # same queries on every rank
+    Q = F.normalize(torch.randn(nq, LQ, H, generator=gq, device=dev), dim=-1)
+    gc = torch.Generator(device=dev).manual_seed(2 + rank)     # this shard's candidates, fresh per step
+    cands = torch.randint(lo, hi, (total, nq, per), generator=gc, device=dev, dtype=torch.int64)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(total)]
+
+    def step(i):
+        cand_global = cands[i]
+        cand_local, inr = cand_global - lo, None
+        ev[i][0].record()
+        scores = ranker.score_candidates(Q, cand_local)
+        ev[i][1].record()
+        top_p, top_s = ranker.topk(scores, cand_global, TOPK if per >= TOPK else per)
+        if world > 1:
+            gs = torch.empty((world,) + tuple(top_s.shape), dtype=top_s.dtype, device=dev)
+            gp = torch.empty((world,) + tuple(top_p.shape), dtype=top_p.dtype, device=dev)
+            dist.all_gather_into_tensor(gs, top_s)
+            dist.all_gather_into_tensor(gp, top_p)
+            from colbert_amd.sharded import merge_gathered
+            top_p, top_s = merge_gathered(gs, gp, TOPK, ranker.topk)
+        return top_p, top_s
+
+    for i in range(args.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, total):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(args.warmup, total)) / args.steps
+    # algorithmic bytes of ONE rerank launch on this rank: doc tokens read once + Q + pid/offset/len + score
+    docs = nq * per
+    alg_bytes = docs * LD * H * esize + nq * LQ * H * 4 + docs * (8 + 12 + 4)
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        res = {
+            "metric": "queries/sec MaxSim rerank, 32q x 180d tokens, dim=128, 1000 docs/query",
+            "value": round(nq * args.steps / el, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"C2: {NQ} queries/GPU x {NCAND} candidates/query, {LQ}x{LD} tokens, dim {H}, "
+                                   f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}",
+                       "queries_per_step": nq, "candidates_per_query": NCAND, "docs_per_gpu": ndocs,
+                       "index_dtype": args.index_dtype, "parallelism": f"doc-shard x{world}"},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "kernel": "k_maxsim_*_h128 (rerank)", "kernel_ms": round(kern_ms, 4),
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,8 @@
+"""colbert_amd -- MI355X-native MaxSim rerank path (drop-in for wuyaoxuehun/colbert's
+``BaseModel.score`` + ``ColbertRanker.rank_forward``).  Importing this package loads libmaxsim.so and fails
+loudly if it has not been built."""
+from . import _lib
+from .ranker import ColbertRanker
+from .scoring import MaxSimModel, score
+
+__all__ = ["ColbertRanker", "MaxSimModel", "score", "_lib"]

@@ -1,0 +1,58 @@
+"""ctypes binding of libmaxsim.so (the C ABI declared in include/maxsim.h).
+
+The library is the product: there is NO CPU or torch fallback.  If the shared object is missing or does not
+export a declared symbol, importing this module raises immediately.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmaxsim.so")
+
+# include/maxsim.h
+F32, F16, BF16 = 0, 1, 2
+MASK_NONE, MASK_I64, MASK_I32, MASK_F32, MASK_U8 = 0, 1, 2, 3, 4
+OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
+
+SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk")
+
+
+class MaxSimError(RuntimeError):
+    def __init__(self, code, where):
+        self.code = code
+        super().__init__(f"{where}: libmaxsim error {code} ({strerror(code)})")
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or colbert_amd/csrc/build.sh (hipcc --offload-arch=gfx950). There is no fallback path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for s in SYMBOLS:
+        if not hasattr(lib, s):
+            raise ImportError(f"{LIB_PATH} does not export {s}")
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64
+    lib.maxsim_version.restype = i32
+    lib.maxsim_version.argtypes = []
+    lib.maxsim_strerror.restype = ctypes.c_char_p
+    lib.maxsim_strerror.argtypes = [i32]
+    lib.maxsim_score_dense.restype = i32
+    lib.maxsim_score_dense.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
+    lib.maxsim_rerank.restype = i32
+    lib.maxsim_rerank.argtypes = [vp, i32, i64, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.maxsim_topk.restype = i32
+    lib.maxsim_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    return lib
+
+
+lib = _load()
+
+
+def strerror(code):
+    return lib.maxsim_strerror(int(code)).decode()
+
+
+def check(code, where):
+    if code != OK:
+        raise MaxSimError(code, where)

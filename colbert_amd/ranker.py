@@ -1,0 +1,159 @@
+"""Host-side mirror of the reference rerank loop, ``ColbertRanker``
+(reference: colbert/ranking/colbert_ranker.py:15-137), on an HBM-resident token index.
+
+What changes against the reference, by design: the index lives in HBM once (no per-query CPU gather, pinned
+buffer, PCIe copy or fp16->fp32 cast pass -- colbert_ranker.py:105-107), there are no padded per-bucket copies
+of D (the fused kernel streams each candidate's real tokens and applies the reference's zero-padding floor
+analytically), and a whole batch of queries is one launch (``rerank_batch``) instead of the per-query Python
+loop of colbert/training/dense_server_client.py:44-48.  ``rank_forward`` keeps the reference's signature,
+asserts and return contract so ``ColbertRetriever.search`` (colbert/indexing/faiss_indexers.py:224-235) can
+call it unchanged.
+"""
+from itertools import accumulate
+
+import torch
+
+from . import _lib, index_io
+from .scoring import _DT, _ptr, _stream
+
+BSIZE = 1 << 14  # colbert_ranker.py:11
+
+
+def torch_percentile(tensor, p):
+    """colbert_ranker.py:238-241."""
+    assert p in range(1, 100 + 1)
+    assert tensor.dim() == 1
+    return tensor.kthvalue(int(p * tensor.size(0) / 100.0)).values.item()
+
+
+class ColbertRanker:
+    """``ColbertRanker(index_path, model=None, dim=None)`` as in colbert_ranker.py:16; ``model`` is accepted for
+    signature compatibility (the fused kernel replaces ``model.score``).  Keyword-only extras:
+
+    parts / parts_doclens : build from in-memory tensors instead of ``index_path``
+    device                : the GPU holding the index
+    index_dtype           : storage dtype in HBM (reference: fp16, colbert_ranker.py:62)
+    pid_offset            : global pid of local doc 0 (doc-sharded multi-GPU)
+    """
+
+    def __init__(self, index_path=None, model=None, dim=None, *, parts=None, parts_doclens=None, device="cuda",
+                 index_dtype=torch.float16, pid_offset=0):
+        if index_path is not None:
+            _, parts_paths, _ = index_io.get_parts(index_path)                # :18
+            parts_doclens = index_io.load_doclens(index_path, flatten=False)  # :22
+            parts = [index_io.load_index_part(f) for f in parts_paths]        # :61-73
+        if parts is None or parts_doclens is None:
+            raise ValueError("give index_path or parts+parts_doclens")
+        self.maxsim_dtype = torch.float32                                     # :20
+        self.parts_doclens = parts_doclens
+        self.model = model
+        self.device = torch.device(device)
+        self.pid_offset = int(pid_offset)
+        doclens = [int(x) for y in parts_doclens for x in y]                  # flatten, utils.py:133
+        self.num_embeddings = sum(doclens)
+        dim = parts[0].size(-1) if dim is None else dim
+        assert index_dtype in _DT
+        # one HBM-resident [num_embeddings, dim] token matrix (no +512 tail: the kernel never reads past a doc)
+        self.tensor = torch.empty(max(self.num_embeddings, 1), dim, dtype=index_dtype, device=self.device)
+        offset = 0
+        for part, dl in zip(parts, parts_doclens):
+            endpos = offset + sum(dl)
+            self.tensor[offset:endpos] = part.to(device=self.device, dtype=index_dtype)
+            offset = endpos
+        self.init_ranker(doclens)
+
+    def init_ranker(self, doclens):                                           # :31-43
+        pfx = [0] + list(accumulate(doclens))
+        self.doclens = torch.tensor(doclens, dtype=torch.int64)
+        self.doclens_pfxsum = torch.tensor(pfx, dtype=torch.int64)
+        self.dim = self.tensor.size(-1)
+        self.strides = [torch_percentile(self.doclens, p) for p in [25, 50, 75]]   # :36
+        self.strides.append(self.doclens.max().item())                              # :39
+        self.strides = sorted(list(set(self.strides)))                              # :40
+        # the bucket stride each doc would be padded to (:90): smallest stride >= doclen
+        assignments = (self.doclens.unsqueeze(1) > torch.tensor(self.strides).unsqueeze(0) + 1e-6).sum(-1)
+        pad_len = torch.tensor(self.strides)[assignments]
+        dev = self.device
+        self.d_doclens = self.doclens.to(dev, torch.int32)
+        self.d_offsets = self.doclens_pfxsum[:-1].contiguous().to(dev)
+        self.d_pad_len = pad_len.to(dev, torch.int32)
+        self.n_docs = len(doclens)
+
+    # ------------------------------------------------------------------------------------------
+    def score_candidates(self, Q, cand_pids, q_len=None):
+        """Q [nq, Lq, h] (token-major), cand_pids [nq, ncand] int64 LOCAL pids (<0 = padding slot)
+        -> scores [nq, ncand] fp32 on the device."""
+        dev = self.device
+        Q = Q.to(device=dev, dtype=torch.float32).contiguous()
+        cand = cand_pids.to(device=dev, dtype=torch.int64).contiguous()
+        nq, Lq, h = Q.shape
+        assert h == self.dim, (h, self.dim)
+        assert cand.dim() == 2 and cand.size(0) == nq
+        ncand = cand.size(1)
+        ql = None if q_len is None else q_len.to(device=dev, dtype=torch.int32).contiguous()
+        scores = torch.empty(nq, ncand, dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib.maxsim_rerank(_ptr(self.tensor), _DT[self.tensor.dtype], self.num_embeddings,
+                                        _ptr(self.d_offsets), _ptr(self.d_doclens), _ptr(self.d_pad_len),
+                                        self.n_docs, _ptr(Q), _ptr(ql), _ptr(cand), nq, ncand, Lq, h,
+                                        _ptr(scores), _stream(dev))
+        if rc == _lib.EEMPTY:
+            raise AssertionError("len(pids) > 0")  # colbert_ranker.py:76
+        _lib.check(rc, "maxsim_rerank")
+        return scores
+
+    def topk(self, scores, pids, k):
+        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k])."""
+        dev = scores.device
+        nq, n = scores.shape
+        out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+        out_p = torch.empty(nq, k, dtype=torch.int64, device=dev)
+        scores = scores.contiguous()
+        pids = None if pids is None else pids.to(device=dev, dtype=torch.int64).contiguous()
+        with torch.cuda.device(dev):
+            rc = _lib.lib.maxsim_topk(_ptr(scores), _ptr(pids), nq, n, k, _ptr(out_s), _ptr(out_p), _stream(dev))
+        _lib.check(rc, "maxsim_topk")
+        return out_p, out_s
+
+    def rerank_batch(self, Q, cand_pids, depth=10, q_len=None):
+        """Batched form of the per-query loop dense_server_client.py:44-48: one launch for all queries.
+        Returns device tensors (pids [nq,k], scores [nq,k]) with k = min(depth, ncand)."""
+        scores = self.score_candidates(Q, cand_pids, q_len)
+        k = min(int(depth), scores.size(1))
+        return self.topk(scores, cand_pids, k)
+
+    # ------------------------------------------------------------------------------------------
+    def rank_forward(self, Q, pids, views=None, depth=10, output_D_embedding=False):
+        """colbert_ranker.py:75-137.  Q is [1, h, Lq] (dim-major, as faiss_indexers.py:232-233 hands it over)."""
+        assert len(pids) > 0                                                  # :76
+        assert Q.size(0) in [1, len(pids)]                                    # :77
+        if Q.size(0) != 1:
+            # the reference's per-candidate-query branch (:103) takes row [0] of an all-pairs result (:112) --
+            # a latent bug that is never exercised (faiss_indexers.py:232-234 always passes one query).
+            raise NotImplementedError("rank_forward with one query per candidate is not exercised by the reference")
+        raw_pids = pids if type(pids) is list else pids.tolist()
+        pids_t = torch.tensor(pids) if type(pids) is list else pids
+        Qt = Q.to(self.device).permute(0, 2, 1)                               # :78, :111 -> [1, Lq, h]
+        cand = pids_t.to(self.device, torch.int64).view(1, -1)
+        scores = self.score_candidates(Qt, cand)
+        k = min(int(depth), len(raw_pids))
+        top_p, top_s = self.topk(scores, cand, k)                             # :128-130
+        if output_D_embedding:                                                # :131-136
+            return self._output_D(top_p[0], k)
+        return top_p[0].tolist(), top_s[0].tolist()
+
+    def _output_D(self, top_pids, k):
+        """colbert_ranker.py:131-136: padded D [k, S, h] and mask of the top docs.  The reference's
+        ``torch.cat(output_D)`` only works when all candidates fall in ONE length bucket; same restriction."""
+        pad = self.d_pad_len[top_pids].to(torch.int64)
+        S = int(pad.max().item())
+        if not bool((pad == S).all()):
+            raise RuntimeError("Sizes of tensors must match except in dimension 0 (candidates span several length buckets)")
+        rows = self.d_offsets[top_pids].unsqueeze(1) + torch.arange(S, device=self.device).unsqueeze(0)
+        mask = torch.arange(S, device=self.device).unsqueeze(0) + 1 <= self.d_doclens[top_pids].unsqueeze(1)
+        rows = rows.clamp(max=max(self.num_embeddings - 1, 0))
+        D = self.tensor[rows].to(self.maxsim_dtype)
+        # slots past the doc end alias the next doc's tokens in the reference view (:49); they are only ever used
+        # under the mask, so they are returned zeroed here
+        D = D * mask.unsqueeze(-1)
+        return top_pids.tolist(), D, mask

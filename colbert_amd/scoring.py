@@ -1,0 +1,61 @@
+"""Host-side mirror of the reference MaxSim operator, ``BaseModel.score``
+(reference: colbert/modeling/BaseModel.py:39-46), backed by ``maxsim_score_dense`` in libmaxsim.so.
+
+``MaxSimModel`` is an object that can be handed to the reference's ``ColbertRanker(model=...)``
+(colbert/ranking/colbert_ranker.py:16,28,111): it exposes exactly ``score(Q, D, q_mask, d_mask)``.
+"""
+import torch
+
+from . import _lib
+
+_DT = {torch.float32: _lib.F32, torch.float16: _lib.F16, torch.bfloat16: _lib.BF16}
+_MDT = {torch.int64: _lib.MASK_I64, torch.int32: _lib.MASK_I32, torch.float32: _lib.MASK_F32,
+        torch.uint8: _lib.MASK_U8, torch.bool: _lib.MASK_U8}
+
+
+def _stream(device):
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def score(Q, D, q_mask, d_mask, *args, **kwargs):
+    """``scores[q, d] = sum_m max_n <Q[q,m]*q_mask[q,m], D[d,n]*d_mask[d,n]>`` on the GPU.
+
+    Same signature, argument meaning and result shape as ``BaseModel.score`` (BaseModel.py:39-46); inputs are
+    borrowed and never mutated; the result is a fresh tensor on the inputs' device whose dtype follows torch's
+    promotion of ``Q * q_mask`` (fp32 for the rerank call, colbert_ranker.py:111-112).  The arithmetic is fp32.
+    """
+    if Q.dim() != 3 or D.dim() != 3 or q_mask.dim() != 2 or d_mask.dim() != 2:
+        raise ValueError("score expects Q[q,m,h], D[d,n,h], q_mask[q,m], d_mask[d,n]")
+    if not Q.is_cuda:
+        raise RuntimeError("colbert_amd.score runs on the GPU only (libmaxsim has no CPU path)")
+    nq, Lq, h = Q.shape
+    nd, Ld, h2 = D.shape
+    if h != h2 or tuple(q_mask.shape) != (nq, Lq) or tuple(d_mask.shape) != (nd, Ld):
+        raise ValueError(f"shape mismatch: Q{tuple(Q.shape)} D{tuple(D.shape)} "
+                         f"q_mask{tuple(q_mask.shape)} d_mask{tuple(d_mask.shape)}")
+    dev = Q.device
+    out_dtype = torch.promote_types(torch.promote_types(Q.dtype, q_mask.dtype), torch.promote_types(D.dtype, d_mask.dtype))
+    cdt = Q.dtype if Q.dtype == D.dtype and Q.dtype in _DT else torch.float32
+    Qc = Q.to(device=dev, dtype=cdt).contiguous()
+    Dc = D.to(device=dev, dtype=cdt).contiguous()
+    mdt = d_mask.dtype if d_mask.dtype in _MDT else torch.float32
+    qm = q_mask.to(device=dev, dtype=mdt).contiguous()
+    dm = d_mask.to(device=dev, dtype=mdt).contiguous()
+    out = torch.empty(nq, nd, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        rc = _lib.lib.maxsim_score_dense(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), nq, nd, Lq, Ld, h, _DT[cdt],
+                                         _MDT[mdt], _ptr(out), _stream(dev))
+    if rc == _lib.EEMPTY:
+        # torch: "max(): Expected reduction dim -1 to have non-zero size" (BaseModel.py:44)
+        raise IndexError("max(): Expected reduction dim 3 to have non-zero size.")
+    _lib.check(rc, "maxsim_score_dense")
+    return out if out_dtype == torch.float32 or not out_dtype.is_floating_point else out.to(out_dtype)
+
+
+class MaxSimModel:
+    """Drop-in for the ``model`` argument of ``ColbertRanker`` (colbert_ranker.py:16,28): only ``score`` is used."""
+    score = staticmethod(score)

@@ -1,0 +1,112 @@
+/*
+ * maxsim.h -- C ABI of libmaxsim.so: MI355X (gfx950) ColBERT late-interaction (MaxSim) rerank path.
+ *
+ * This is the drop-in boundary for ONE hot path of wuyaoxuehun/colbert (a pure-Python/torch code base, so
+ * there is no reference FFI to mirror; each entry point names the reference Python it replaces, paths
+ * relative to the reference checkout):
+ *
+ *   maxsim_score_dense  <- BaseModel.score(Q, D, q_mask, d_mask)      colbert/modeling/BaseModel.py:39-46
+ *   maxsim_rerank       <- the gather/pad/mask/score body of
+ *                          ColbertRanker.rank_forward                 colbert/ranking/colbert_ranker.py:88-118
+ *                          (batched over queries: replaces the per-query loop
+ *                           colbert/training/dense_server_client.py:44-48)
+ *   maxsim_topk         <- sort(descending)+[:depth]                  colbert/ranking/colbert_ranker.py:128-130
+ *                          (also the per-query merge after the doc-sharded RCCL all-gather)
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensors); the library allocates
+ *     nothing and keeps no state between calls; it is re-entrant per stream;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is asynchronous on it;
+ *   - return value: MAXSIM_OK (0) or a negative MAXSIM_E* code; no exceptions cross the ABI;
+ *   - all tensors are dense row-major.
+ */
+#ifndef MAXSIM_H
+#define MAXSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MAXSIM_VERSION 100 /* 0.1.0 */
+
+/* element types of Q / D / index */
+#define MAXSIM_F32 0
+#define MAXSIM_F16 1
+#define MAXSIM_BF16 2
+
+/* element types of the mask tensors of maxsim_score_dense */
+#define MAXSIM_MASK_NONE 0 /* both mask pointers ignored: all ones */
+#define MAXSIM_MASK_I64 1  /* what rank_forward passes, colbert_ranker.py:111-112 */
+#define MAXSIM_MASK_I32 2
+#define MAXSIM_MASK_F32 3 /* what test_score passes, BaseModel.py:73 */
+#define MAXSIM_MASK_U8 4  /* torch.bool / uint8 */
+
+/* error codes */
+#define MAXSIM_OK 0
+#define MAXSIM_EINVAL -1  /* bad argument (null pointer, negative size, unknown dtype) */
+#define MAXSIM_EEMPTY -2  /* empty candidate list / empty doc axis: the reference asserts or raises there
+                             (colbert_ranker.py:76; max over an empty dim at BaseModel.py:44) */
+#define MAXSIM_ERANGE -3  /* size outside what the kernels support (see each function) */
+#define MAXSIM_ELAUNCH -4 /* the HIP runtime refused the launch (hipGetLastError != hipSuccess) */
+
+int maxsim_version(void);
+const char* maxsim_strerror(int code);
+
+/*
+ * All-pairs MaxSim, BaseModel.py:39-46:
+ *   out[q, d] = sum_m max_n  dot( Q[q,m,:] * q_mask[q,m] ,  D[d,n,:] * d_mask[d,n] )
+ * Masked tokens are zeroed (they contribute similarity 0 to the max -- a floor -- and 0 to the sum).
+ *
+ *   Q       [nq, Lq, h]  element type `dtype`
+ *   D       [nd, Ld, h]  element type `dtype`
+ *   q_mask  [nq, Lq], d_mask [nd, Ld]  element type `mask_dtype` (both), any numeric values
+ *   out     [nq, nd] float32 (the arithmetic is fp32 whatever `dtype` is)
+ * nq == 0 or nd == 0 is a no-op; Lq == 0 writes zeros; Ld == 0 -> MAXSIM_EEMPTY; h >= 0.
+ * Fast path (f32-input MFMA, LDS-DMA staged doc tiles): dtype F32, h == 128, Lq <= 32.
+ * Every other shape runs the generic kernel.
+ */
+int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
+                       int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, void* stream);
+
+/*
+ * Fused ragged rerank, the body of rank_forward (colbert_ranker.py:88-118) for a batch of queries, with the
+ * token index resident in HBM and no padded copy of D:
+ *   scores[q, c] = sum_{m < q_len[q]}  max( floor_c , max_{t < doclens[pid]} dot(Q[q,m,:], index[tok_offsets[pid]+t,:]) )
+ *   pid = cand_pids[q, c];   floor_c = 0 if pad_len != NULL && pad_len[pid] > doclens[pid] else -inf
+ * `pad_len[pid]` is the stride S_g of the length bucket the reference would gather the doc at
+ * (colbert_ranker.py:90): the reference's zero-masked padding slots floor the max at 0 exactly when
+ * doclen < S_g.  pad_len == NULL means "no padding anywhere" (no floor).
+ *
+ *   index       [n_tokens, h]  element type index_dtype (the reference stores fp16, colbert_ranker.py:62)
+ *   tok_offsets [n_docs] int64  first token row of each doc (doclens prefix sum, colbert_ranker.py:32)
+ *   doclens     [n_docs] int32
+ *   pad_len     [n_docs] int32 or NULL
+ *   Q           [nq, Lq, h] float32 (token-major; the Python shim undoes the reference's [1,h,Lq] permute)
+ *   q_len       [nq] int32 or NULL (= Lq for every query); tokens m >= q_len[q] are dropped
+ *               (what keep_nonzero does before search(), training_utils.py:48-53)
+ *   cand_pids   [nq, ncand] int64; an entry < 0 or >= n_docs is a padding slot: its score is -inf
+ *   scores      [nq, ncand] float32
+ * A doc with doclens == 0 scores 0.  ncand == 0 -> MAXSIM_EEMPTY (colbert_ranker.py:76).
+ * Fast paths: h == 128, Lq <= 32, index F32 (f32-input MFMA) or F16/BF16 (16-bit MFMA, Q split hi+lo).
+ */
+int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,
+                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const float* Q,
+                  const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
+                  float* scores, void* stream);
+
+/*
+ * Per-query top-k by score, descending (colbert_ranker.py:128-130); ties broken by lower position in the
+ * candidate list (the reference's torch.sort is unstable, so any tie order is conforming).
+ *   scores [nq, ncand] float32; pids [nq, ncand] int64 or NULL (then positions 0..ncand-1 are returned)
+ *   out_scores [nq, k] float32, out_pids [nq, k] int64; if k > ncand the tail is (-inf, -1).
+ * 1 <= ncand <= 16384 (the reference's BSIZE, colbert_ranker.py:11), k >= 1.
+ */
+int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
+                int64_t* out_pids, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAXSIM_H */

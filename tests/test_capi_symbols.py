@@ -1,0 +1,69 @@
+"""CPU: libmaxsim.so loads and exports every symbol include/maxsim.h declares; argument validation that
+returns before any launch (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from colbert_amd import _lib
+    return _lib
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "maxsim.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(maxsim_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    syms = declared_symbols()
+    assert set(syms) == set(lib.SYMBOLS)
+    raw = ctypes.CDLL(lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), s
+
+
+def test_version_and_strerror(lib):
+    assert lib.lib.maxsim_version() == 100
+    assert lib.strerror(0) == "ok"
+    for code in (-1, -2, -3, -4):
+        assert lib.strerror(code) not in ("ok", "unknown error")
+
+
+def test_validation_without_launch(lib):
+    L = lib.lib
+    # negative sizes / unknown dtypes
+    assert L.maxsim_score_dense(None, None, None, None, -1, 1, 1, 1, 1, 0, 0, None, None) == lib.EINVAL
+    assert L.maxsim_score_dense(None, None, None, None, 1, 1, 1, 1, 1, 9, 0, None, None) == lib.EINVAL
+    assert L.maxsim_score_dense(None, None, None, None, 1, 1, 1, 1, 1, 0, 9, None, None) == lib.EINVAL
+    # empty outputs are no-ops, empty doc axis is the reference's max-over-empty error
+    assert L.maxsim_score_dense(None, None, None, None, 0, 5, 1, 1, 1, 0, 0, None, None) == lib.OK
+    assert L.maxsim_score_dense(None, None, None, None, 2, 2, 1, 0, 1, 0, 0, None, None) == lib.EEMPTY
+    assert L.maxsim_score_dense(None, None, None, None, 2, 2, 1, 1, 1, 0, 0, None, None) == lib.EINVAL  # null out
+    # rerank: empty candidate list = assert len(pids) > 0 (colbert_ranker.py:76)
+    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, None, None, 1, 0, 32, 128, None, None) == lib.EEMPTY
+    assert L.maxsim_rerank(None, 7, 0, None, None, None, 0, None, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
+    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
+    # topk
+    assert L.maxsim_topk(None, None, 1, 0, 1, None, None, None) == lib.EEMPTY
+    assert L.maxsim_topk(None, None, 1, 20000, 1, None, None, None) == lib.ERANGE
+    assert L.maxsim_topk(None, None, 1, 10, 0, None, None, None) == lib.EINVAL
+    assert L.maxsim_topk(None, None, 1, 10, 1, None, None, None) == lib.EINVAL
+
+
+def test_missing_library_fails_loudly(tmp_path, monkeypatch):
+    """The product has no fallback: a missing .so is an ImportError, not a silent CPU path."""
+    import importlib.util
+    src = os.path.join(ROOT, "colbert_amd", "_lib.py")
+    dst = tmp_path / "_lib_copy.py"
+    dst.write_text(open(src).read())
+    spec = importlib.util.spec_from_file_location("_lib_copy", dst)
+    mod = importlib.util.module_from_spec(spec)
+    with pytest.raises(ImportError):
+        spec.loader.exec_module(mod)

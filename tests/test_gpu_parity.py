@@ -1,0 +1,302 @@
+"""GPU parity tests: the HIP path (through the C ABI of libmaxsim.so) against the CPU oracle and the golden
+vectors.  Tolerances: fp32 scores |d| <= 1e-4 absolute (scores have magnitude <= Lq = 32), as stated in
+BASELINE/SURVEY 8c; 16-bit-input paths |d| <= 1e-3 against the oracle run in fp32 on identically rounded inputs."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ATOL32 = 1e-4
+ATOL16 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import colbert_amd
+    return colbert_amd
+
+
+def nrm(gen, *shape):
+    return F.normalize(torch.randn(*shape, generator=gen), dim=-1)
+
+
+# ------------------------------------------------------------------------------------------------------
+# score(): the operator seam, BaseModel.py:39-46
+# ------------------------------------------------------------------------------------------------------
+def test_kat_test_score(ca, golden):
+    g = golden("kat_test_score")
+    out = ca.score(g["Q"].cuda(), g["D"].cuda(), g["q_mask"].cuda(), g["d_mask"].cuda())
+    assert out.dtype == torch.float32 and out.is_cuda
+    assert out.cpu().tolist() == [[21.0, 41.0]]            # BaseModel.py:70-75
+
+
+def test_zero_floor(ca, golden):
+    g = golden("zero_floor")
+    Q, D, qm = g["Q"].cuda(), g["D"].cuda(), g["q_mask"].cuda()
+    assert ca.score(Q, D, qm, g["d_mask_full"].cuda()).item() == -1.0
+    assert ca.score(Q, D, qm, g["d_mask_floor"].cuda()).item() == 0.0
+
+
+@pytest.mark.parametrize("name", ["c1_1q_10d", "allpairs_4x6_masked", "allpairs_4x6_floatmask", "c4_multiview"])
+def test_dense_goldens(ca, golden, name):
+    g = golden(name)
+    Qc, Dc = g["Q"].cuda(), g["D"].cuda()
+    Q0, D0 = Qc.clone(), Dc.clone()
+    out = ca.score(Qc, Dc, g["q_mask"].cuda(), g["d_mask"].cuda())
+    assert out.shape == g["expected"].shape and out.dtype == g["expected"].dtype
+    torch.testing.assert_close(out.cpu(), g["expected"], rtol=0, atol=ATOL32)
+    assert torch.equal(Qc, Q0) and torch.equal(Dc, D0)      # inputs are borrowed, never mutated
+
+
+def test_c5_bf16_golden(ca, golden):
+    g = golden("c5_bf16_768")
+    out = ca.score(g["Q"].cuda(), g["D"].cuda(), g["q_mask"].cuda(), g["d_mask"].cuda())
+    # torch promotion: bf16 * int64 -> bf16 (the reference returns the promoted dtype)
+    assert out.dtype == torch.bfloat16
+    out32 = ca.score(g["Q"].cuda(), g["D"].cuda(), g["q_mask"].float().cuda(), g["d_mask"].float().cuda())
+    assert out32.dtype == torch.float32
+    torch.testing.assert_close(out32.cpu(), g["expected"], rtol=0, atol=ATOL16)
+
+
+def test_model_object_is_dropin(ca):
+    from oracle.maxsim_oracle import ref_score
+    gen = torch.Generator().manual_seed(11)
+    Q, D = nrm(gen, 1, 32, 128), nrm(gen, 37, 50, 128)
+    mask = (torch.arange(50) + 1).unsqueeze(0) <= torch.randint(1, 51, (37, 1), generator=gen)
+    m = ca.MaxSimModel()
+    # exactly the call colbert_ranker.py:111-112 makes
+    out = m.score(Q=Q.cuda(), D=D.cuda(), q_mask=torch.ones((1, 32), dtype=torch.long).cuda(),
+                  d_mask=mask.to(torch.long).cuda())[0].cpu()
+    exp = ref_score(Q, D, torch.ones(1, 32, dtype=torch.long), mask.long())[0]
+    torch.testing.assert_close(out, exp, rtol=0, atol=ATOL32)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9, 16), (2, 33, 40, 65, 128), (1, 1, 1, 1, 1), (2, 32, 3, 31, 128),
+                                   (2, 32, 3, 33, 128), (5, 17, 4, 64, 128), (1, 40, 2, 10, 64)])
+@pytest.mark.parametrize("mask_dtype", [torch.int64, torch.float32, torch.bool, torch.int32])
+def test_dense_random_shapes(ca, shape, mask_dtype):
+    from oracle.maxsim_oracle import ref_score
+    nq, Lq, nd, Ld, h = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    Q, D = nrm(gen, nq, Lq, h), nrm(gen, nd, Ld, h)
+    qm = (torch.rand(nq, Lq, generator=gen) > 0.2).to(mask_dtype)
+    dm = (torch.rand(nd, Ld, generator=gen) > 0.3).to(mask_dtype)
+    out = ca.score(Q.cuda(), D.cuda(), qm.cuda(), dm.cuda())
+    exp = ref_score(Q, D, qm, dm)
+    assert out.dtype == exp.dtype
+    torch.testing.assert_close(out.cpu(), exp, rtol=0, atol=ATOL32)
+
+
+def test_dense_errors(ca):
+    Q = torch.zeros(1, 2, 4).cuda()
+    with pytest.raises(IndexError):           # max over an empty doc axis, BaseModel.py:44
+        ca.score(Q, torch.zeros(2, 0, 4).cuda(), torch.ones(1, 2).cuda(), torch.ones(2, 0).cuda())
+    with pytest.raises(ValueError):
+        ca.score(Q, torch.zeros(2, 3, 5).cuda(), torch.ones(1, 2).cuda(), torch.ones(2, 3).cuda())
+    out = ca.score(torch.zeros(2, 0, 4).cuda(), torch.zeros(3, 2, 4).cuda(), torch.ones(2, 0).cuda(), torch.ones(3, 2).cuda())
+    assert out.shape == (2, 3) and float(out.abs().sum()) == 0.0
+
+
+def test_f32_mfma_is_an_exact_fmaf_chain(ca):
+    """Bit-exactness of the flagship kernel: its scores equal a CPU fp32 fmaf chain walked in the kernel's
+    k-order, max over tokens, butterfly sum over query tokens -- no tolerance."""
+    from oracle.maxsim_oracle import score_chain_f32
+    gen = torch.Generator().manual_seed(3)
+    Q, D = nrm(gen, 1, 32, 128), nrm(gen, 3, 45, 128)
+    ones_q, ones_d = torch.ones(1, 32), torch.ones(3, 45)
+    order = []
+    for s in range(4):
+        for u in range(4):
+            for t in range(4):
+                order += [32 * s + 8 * u + t, 32 * s + 8 * u + 4 + t]
+    # per (q-token, doc) maxima with the chain oracle, then the kernel's butterfly sum over 32 lanes
+    Qm, Dm = Q.numpy(), D.numpy()
+    acc = np.zeros((3, 32, 45), dtype=np.float32)
+    for k in order:
+        prod = Qm[0, None, :, None, k].astype(np.float64) * Dm[:, None, :, k].astype(np.float64)
+        acc = (prod + acc.astype(np.float64)).astype(np.float32)
+    mx = acc.max(-1)                                    # [3, 32]
+    exp = []
+    for d in range(3):
+        v = mx[d].copy()
+        for o in (16, 8, 4, 2, 1):
+            v = (v + v[np.arange(32) ^ o]).astype(np.float32)
+        exp.append(v[0])
+    out = ca.score(Q.cuda(), D.cuda(), ones_q.cuda(), ones_d.cuda()).cpu().numpy()[0]
+    assert out.tobytes() == np.array(exp, dtype=np.float32).tobytes()
+    # and the generic chain helper agrees to rounding
+    np.testing.assert_allclose(score_chain_f32(Q, D, ones_q, ones_d, order)[0], out, rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# rank_forward / fused ragged rerank: colbert_ranker.py:75-137
+# ------------------------------------------------------------------------------------------------------
+def _golden_ranker(ca, g, dtype):
+    parts = [g["part0"], g["part1"]]
+    pdl = [g["doclens0"].tolist(), g["doclens1"].tolist()]
+    return ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=128, index_dtype=dtype)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_ragged_rerank_golden(ca, golden, dtype):
+    g = golden("ragged_rerank_64")
+    r = _golden_ranker(ca, g, dtype)
+    assert r.strides == g["strides"].tolist()
+    assert torch.equal(r.d_pad_len.cpu().long(), g["pad_len"])
+    pids = g["pids"]
+    for key, exp in (("Q", "expected_scores"), ("Q_neg", "expected_scores_neg")):
+        sc = r.score_candidates(g[key].permute(0, 2, 1), pids.view(1, -1))
+        torch.testing.assert_close(sc.cpu()[0], g[exp], rtol=0, atol=ATOL32)
+    tp, ts = r.rank_forward(g["Q"], pids.tolist(), depth=10)
+    assert isinstance(tp, list) and isinstance(ts, list) and isinstance(tp[0], int) and isinstance(ts[0], float)
+    assert tp == g["top10_pids"].tolist()
+    np.testing.assert_allclose(ts, g["top10_scores"].numpy(), rtol=0, atol=ATOL32)
+    # LongTensor pids and depth > n
+    tp2, ts2 = r.rank_forward(g["Q"].cuda(), pids[:7], depth=10)
+    assert len(tp2) == 7 and ts2 == sorted(ts2, reverse=True)
+
+
+def test_rank_forward_asserts(ca, golden):
+    g = golden("ragged_rerank_64")
+    r = _golden_ranker(ca, g, torch.float16)
+    with pytest.raises(AssertionError):
+        r.rank_forward(g["Q"], [], depth=3)                         # colbert_ranker.py:76
+    with pytest.raises(AssertionError):
+        r.rank_forward(g["Q"].expand(3, -1, -1), [1, 2], depth=3)   # colbert_ranker.py:77
+
+
+def _random_index(gen, ndocs, h, lo, hi, dtype=torch.float16):
+    doclens = torch.randint(lo, hi + 1, (ndocs,), generator=gen).tolist()
+    half = ndocs // 2
+    pdl = [doclens[:half], doclens[half:]]
+    parts = [nrm(gen, sum(d), h).to(dtype) for d in pdl]
+    return parts, pdl
+
+
+@pytest.mark.parametrize("cfg", [
+    dict(ndocs=300, h=128, lo=1, hi=180, nq=5, ncand=97, Lq=32, dtype=torch.float32),
+    dict(ndocs=300, h=128, lo=170, hi=180, nq=3, ncand=64, Lq=20, dtype=torch.float32),
+    dict(ndocs=64, h=128, lo=8, hi=8, nq=4, ncand=64, Lq=8, dtype=torch.float32),      # multi-view shape
+    dict(ndocs=200, h=128, lo=1, hi=90, nq=3, ncand=50, Lq=32, dtype=torch.float16),
+    dict(ndocs=40, h=64, lo=1, hi=40, nq=2, ncand=30, Lq=12, dtype=torch.float32),      # generic kernel
+    dict(ndocs=12, h=768, lo=100, hi=256, nq=2, ncand=12, Lq=32, dtype=torch.bfloat16),
+])
+def test_rerank_random_vs_oracle(ca, cfg):
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(cfg["ndocs"] + cfg["h"])
+    parts, pdl = _random_index(gen, cfg["ndocs"], cfg["h"], cfg["lo"], cfg["hi"], cfg["dtype"])
+    ref = RefRanker(parts, pdl, dim=cfg["h"], index_dtype=cfg["dtype"])
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=cfg["h"], index_dtype=cfg["dtype"])
+    assert r.strides == ref.strides
+    Q = nrm(gen, cfg["nq"], cfg["Lq"], cfg["h"])
+    cand = torch.stack([torch.randperm(cfg["ndocs"], generator=gen)[:cfg["ncand"]] for _ in range(cfg["nq"])])
+    sc = r.score_candidates(Q, cand).cpu()
+    atol = ATOL32 if cfg["dtype"] != torch.bfloat16 else ATOL16
+    for qi in range(cfg["nq"]):
+        exp = ref.all_scores(Q[qi:qi + 1].permute(0, 2, 1), cand[qi].tolist())
+        torch.testing.assert_close(sc[qi], exp, rtol=0, atol=atol)
+    # batched top-k agrees with the reference's per-query rank_forward
+    tp, ts = r.rerank_batch(Q, cand, depth=10)
+    for qi in range(cfg["nq"]):
+        ep, es = ref.rank_forward(Q[qi:qi + 1].permute(0, 2, 1), cand[qi].tolist(), depth=10)
+        np.testing.assert_allclose(ts[qi].cpu().numpy(), np.array(es), rtol=0, atol=atol)
+        assert set(tp[qi].tolist()) == set(ep) or np.allclose(sorted(es)[:1], sorted(ts[qi].tolist())[:1], atol=atol)
+
+
+def test_rerank_edge_cases(ca):
+    """padding slots, empty docs, q_len, one-token docs, the last doc of the index, duplicates, ncand = 1."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(77)
+    doclens = [1, 0, 33, 32, 31, 180, 0, 2, 64, 1]
+    parts = [nrm(gen, sum(doclens), 128)]
+    r = ca.ColbertRanker(parts=parts, parts_doclens=[doclens], dim=128, index_dtype=torch.float32)
+    Q = nrm(gen, 2, 32, 128)
+    cand = torch.tensor([[9, -1, 1, 5, 5, 0, 3, 2, 4, 6, 7, 8, 100, 9], [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, -5, 9, 9, 9]])
+    q_len = torch.tensor([32, 5], dtype=torch.int32)
+    sc = r.score_candidates(Q, cand, q_len=q_len).cpu()
+    offs = r.doclens_pfxsum
+    for qi in range(2):
+        ql = int(q_len[qi])
+        for j, pid in enumerate(cand[qi].tolist()):
+            if pid < 0 or pid >= len(doclens):
+                assert sc[qi, j] == float("-inf")
+            elif doclens[pid] == 0:
+                assert sc[qi, j] == 0.0
+            else:
+                e = ragged_scores_f64(parts[0], doclens, offs, r.d_pad_len.cpu(), Q[qi, :ql], [pid])[0]
+                assert abs(sc[qi, j].item() - e) <= ATOL32, (qi, j, pid)
+    one = r.score_candidates(Q[:1], torch.tensor([[5]])).cpu()
+    assert abs(one[0, 0] - sc[0, 3]) == 0.0                   # duplicates / batch composition: bitwise equal
+    assert sc[0, 3] == sc[0, 4]
+
+
+# ------------------------------------------------------------------------------------------------------
+# top-k: colbert_ranker.py:128-130
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ncand,k", [(1, 1), (7, 3), (1000, 100), (1000, 10), (1024, 1024), (1025, 5), (16384, 100),
+                                      (5, 9)])
+def test_topk_vs_torch(ca, ncand, k):
+    gen = torch.Generator().manual_seed(ncand + k)
+    nq = 3
+    s = torch.randn(nq, ncand, generator=gen)
+    s[0, : ncand // 2] = s[0, ncand // 2: 2 * (ncand // 2)]     # ties
+    if ncand > 3:
+        s[1, 2] = float("-inf")
+    pids = torch.randint(0, 10 ** 12, (nq, ncand), generator=gen)
+    r = ca.ColbertRanker(parts=[torch.zeros(4, 8)], parts_doclens=[[1, 1, 1, 1]], dim=8)
+    tp, ts = r.topk(s.cuda(), pids.cuda(), k)
+    kk = min(k, ncand)
+    es, ei = torch.sort(s, dim=1, descending=True, stable=True)
+    assert torch.equal(ts.cpu()[:, :kk], es[:, :kk])
+    assert torch.equal(tp.cpu()[:, :kk], torch.gather(pids, 1, ei[:, :kk]))     # stable: lower position first
+    if k > ncand:
+        assert bool((ts.cpu()[:, ncand:] == float("-inf")).all()) and bool((tp.cpu()[:, ncand:] == -1).all())
+    tp2, _ = r.topk(s.cuda(), None, kk)
+    assert torch.equal(tp2.cpu(), ei[:, :kk])
+
+
+# ------------------------------------------------------------------------------------------------------
+# BASELINE config C2 at full candidate-batch size: size-independent properties
+# ------------------------------------------------------------------------------------------------------
+def test_c2_full_batch_properties(ca):
+    """256 queries x 1000 candidates, 32 x 180 tokens, dim 128 fp32 (BASELINE configs[1]) on a 20k-doc index:
+    (i) a sample of scores against the CPU oracle, (ii) invariance to candidate order and batch composition
+    (bitwise), (iii) top-k sorted and drawn from the candidates, (iv) a doc queried with its own first 32
+    tokens scores ~32 (unit vectors: each query token finds itself)."""
+    from oracle.maxsim_oracle import ref_score
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(1234)
+    ndocs, L, h, nq, ncand = 20000, 180, 128, 256, 1000
+    idx = F.normalize(torch.randn(ndocs * L, h, generator=gen, device=dev), dim=-1)
+    r = ca.ColbertRanker(parts=[idx], parts_doclens=[[L] * ndocs], dim=h, index_dtype=torch.float32)
+    assert r.strides == [L]
+    Q = F.normalize(torch.randn(nq, 32, h, generator=gen, device=dev), dim=-1)
+    cand = torch.stack([torch.randperm(ndocs, generator=gen, device=dev)[:ncand] for _ in range(nq)])
+    sc = r.score_candidates(Q, cand)
+    assert sc.shape == (nq, ncand) and bool(torch.isfinite(sc).all())
+    # (i) oracle on a sample
+    D3 = idx.view(ndocs, L, h)
+    for qi in (0, 17, 255):
+        cols = torch.arange(0, ncand, 53, device=dev)
+        Dq = D3[cand[qi, cols]].cpu()
+        exp = ref_score(Q[qi:qi + 1].cpu(), Dq, torch.ones(1, 32, dtype=torch.long), torch.ones(len(cols), L, dtype=torch.long))[0]
+        torch.testing.assert_close(sc[qi, cols].cpu(), exp, rtol=0, atol=ATOL32)
+    # (ii) permutation / batch-composition invariance, bitwise
+    perm = torch.randperm(ncand, generator=gen, device=dev)
+    sc_p = r.score_candidates(Q, cand[:, perm])
+    assert torch.equal(sc_p, sc[:, perm])
+    sc_sub = r.score_candidates(Q[100:103], cand[100:103, :77])
+    assert torch.equal(sc_sub, sc[100:103, :77])
+    # (iii) top-k
+    tp, ts = r.rerank_batch(Q, cand, depth=100)
+    assert tp.shape == (nq, 100)
+    assert bool((ts[:, :-1] >= ts[:, 1:]).all())
+    es, ei = torch.sort(sc, dim=1, descending=True, stable=True)
+    assert torch.equal(ts, es[:, :100]) and torch.equal(tp, torch.gather(cand, 1, ei[:, :100]))
+    # (iv) self-retrieval
+    own = D3[cand[:, 0], :32].contiguous()
+    s_own = r.score_candidates(own, cand[:, :1])
+    torch.testing.assert_close(s_own.cpu(), torch.full((nq, 1), 32.0), rtol=0, atol=1e-3)
