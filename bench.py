@@ -38,11 +38,23 @@ def build_index(ndocs, dev, seed, dtype):
     return idx
 
 
+def host_cores():
+    """Cores this process may actually use: the cgroup CPU quota (the GPU box gives 16 of 256), else affinity."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def cpu_baseline(seconds=12.0):
     """The oracle restatement of the reference's score() (BaseModel.py:39-46) on the host cores: the reference's
     unit of work, 1 query x 1000 docs per call (colbert_ranker.py:111-112), fp32."""
     from oracle.maxsim_oracle import ref_score
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(0)
     Q = F.normalize(torch.randn(1, LQ, H, generator=gen), dim=-1)
@@ -118,11 +130,8 @@ def main():
         ev[i][1].record()
         top_p, top_s = ranker.topk(scores, cand_global, TOPK if per >= TOPK else per)
         if world > 1:
-            gs = torch.empty((world,) + tuple(top_s.shape), dtype=top_s.dtype, device=dev)
-            gp = torch.empty((world,) + tuple(top_p.shape), dtype=top_p.dtype, device=dev)
-            dist.all_gather_into_tensor(gs, top_s)
-            dist.all_gather_into_tensor(gp, top_p)
-            from colbert_amd.sharded import merge_gathered
+            from colbert_amd.sharded import all_gather_topk, merge_gathered
+            gs, gp = all_gather_topk(top_s, top_p, world)
             top_p, top_s = merge_gathered(gs, gp, TOPK, ranker.topk)
         return top_p, top_s
 
@@ -150,6 +159,18 @@ def main():
     alg_bytes = docs * LD * H * esize + nq * LQ * H * 4 + docs * (8 + 12 + 4)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
+    # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
+    # MI355X_MICROARCH.md prescribes; summary committed under profiles/ by tools/summarize_profile.py)
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", f"r01_c2_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
+    if world == 1 and ndocs == 1_000_000 and os.path.exists(pmc):
+        try:
+            for k, v in json.load(open(pmc)).items():
+                if "maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
+                    traffic = int(v["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] + v.get("hbm_write_bytes_per_launch(WRITE_SIZE*1024)", 0))
+        except (OSError, ValueError):
+            traffic = None
+
     if rank == 0:
         res = {
             "metric": "queries/sec MaxSim rerank, 32q x 180d tokens, dim=128, 1000 docs/query",
@@ -161,7 +182,7 @@ def main():
                        "queries_per_step": nq, "candidates_per_query": NCAND, "docs_per_gpu": ndocs,
                        "index_dtype": args.index_dtype, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_maxsim_*_h128 (rerank)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }

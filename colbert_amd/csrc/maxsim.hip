@@ -13,6 +13,7 @@
 // gfx950 only.  No CUDA, no hipify, no dual paths.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "maxsim.h"
 
@@ -183,29 +184,30 @@ struct TileIt {
 // =============================================================================================
 // Flagship kernel: fp32 token matrix, h = 128, Lq <= 32.  f32-input MFMA 32x32x2 (exact f32).
 //
-// LDS per wave: TA tile groups x 4 slabs x 4 KiB.  A slab = 32 token rows x 32 dims (128 B per row, one
-// full cache line per row), written by 4 LDS-DMA instructions of 8 rows each.  Source chunk j of row m is
-// stored at chunk position j ^ ((m >> 1) & 7), which makes the ds_read_b128 operand reads conflict-free.
+// LDS per wave: a ring of NSLOT slabs of 4 KiB.  A slab = 32 token rows x 32 dims (128 B per row, one
+// full cache line per row), written by 4 LDS-DMA instructions of 8 rows each; a 32-token tile = 4 slabs.
+// Source chunk j of row m is stored at chunk position j ^ ((m >> 1) & 7), which makes the ds_read_b128
+// operand reads conflict-free.  The fetch pointer runs exactly NSLOT slabs ahead of the consume pointer:
+// the slab fetched at step c lands in the slot that step c has just read into registers.
 //
 // MFMA roles: A = doc tokens (row i = lane & 31, k = lane >> 5), B = query tokens (col j = lane & 31).
 // The accumulator then holds, per lane, ONE query token and 16 doc tokens, so max-over-doc-tokens is an
 // in-lane max over the 16 accumulator registers plus one exchange between the two lane halves.
 // k-order of the fmaf chain: for slab s, u in 0..3, t in 0..3: dims 32s+8u+t then 32s+8u+4+t.
 // =============================================================================================
-template <int MODE, int WAVES, int TA>
+template <int MODE, int WAVES, int NSLOT, int ABLATE = 0>  // ABLATE (diagnostic builds only): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_f32_h128(KARGS_DECL) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   constexpr int ROWB = 512;            // bytes per token row
   constexpr int SLAB = 4096;           // bytes per slab
-  constexpr int GROUP = 4 * SLAB;      // one 32-token tile
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   const int qi = blockIdx.x / p.nchunk;
   const int chunk = blockIdx.x - qi * p.nchunk;
   const int c_begin = chunk * p.dpw;
   const int c_end = min(p.ncand, c_begin + p.dpw);
-  char* const wlds = lds + wave * (TA * GROUP);
+  char* const wlds = lds + wave * (NSLOT * SLAB);
 
   // ---- query tile into registers, MFMA B layout -------------------------------------------------
   const int n = lane & 31, kh = lane >> 5;
@@ -244,65 +246,75 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_f32_h128(KARGS_DECL) {
   const char* const tok = (const char*)p.index;
 
   // per-lane byte offsets (relative to the doc's first row) of the 4 DMA row groups of a tile
-  auto tile_offsets = [&](const Doc& d, int t, uint32_t (&off)[4]) {
+  uint32_t foff[4] = {0, 0, 0, 0};
+  const char* fbase = tok;
+  auto fetch_tile_setup = [&]() {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       int mm = 8 * i + drow;
-      int r = min(t * 32 + mm, d.nfetch - 1);  // rows past the doc end re-read its last token: max unchanged
-      off[i] = (uint32_t)r * ROWB + 16u * (uint32_t)(dchunk ^ ((mm >> 1) & 7));
+      int r = min(F.t * 32 + mm, F.d.nfetch - 1);  // rows past the doc end re-read its last token: max unchanged
+      foff[i] = (uint32_t)r * ROWB + 16u * (uint32_t)(dchunk ^ ((mm >> 1) & 7));
     }
+    fbase = tok + F.d.row0 * ROWB;
   };
-  auto issue_slab = [&](const char* base, const uint32_t (&off)[4], int g, int s) {
-    char* l = wlds + g * GROUP + s * SLAB;
+  auto issue_slab = [&](int fs, int slot) {
+    if (ABLATE == 2) return;
+    char* l = wlds + slot * SLAB;
 #pragma unroll
     for (int i = 0; i < 4; ++i)
-      __builtin_amdgcn_global_load_lds(GPTR(base + (uint32_t)(off[i] + (uint32_t)(s * 128))), LPTR(l + i * 1024), 16,
-                                       0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(fbase + (uint32_t)(foff[i] + (uint32_t)(fs * 128))), LPTR(l + i * 1024),
+                                       16, 0, 0);
   };
 
-  // ---- prologue: TA whole tiles in flight --------------------------------------------------------
-  uint32_t foff[4];
+  // ---- prologue: NSLOT slabs in flight ------------------------------------------------------------
+  bool prev_issued = false;
 #pragma unroll
-  for (int a = 0; a < TA; ++a) {
+  for (int j = 0; j < NSLOT; ++j) {
+    const int fs = j & 3;
+    if (fs == 0 && j > 0 && F.valid) F.advance(p, qi);
     if (F.valid) {
-      tile_offsets(F.d, F.t, foff);
-      const char* base = tok + F.d.row0 * ROWB;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) issue_slab(base, foff, a, s);
-      F.advance(p, qi);
+      if (fs == 0) fetch_tile_setup();
+      issue_slab(fs, j);
     }
+    prev_issued = F.valid;
   }
 
   float rmax = NEG_INF;
   float myscore = 0.0f;
   int jdoc = 0;
-  int g = 0;
+  int slot = 0;
 
   while (C.valid) {
-    const bool steady = F.valid;  // tile T+TA exists: it is fetched into the slots this tile frees
-    const char* fbase = tok;
-    if (steady) {
-      tile_offsets(F.d, F.t, foff);
-      fbase = tok + F.d.row0 * ROWB;
-    }
     float mv = 1.0f;
     if (MODE == MODE_DENSE && p.mask_dtype != MAXSIM_MASK_NONE) {
       int r = min(C.t * 32 + m, C.d.nfetch - 1);
       mv = load_mask(p.d_mask, p.mask_dtype, C.d.row0 + r);
     }
     f32x16 acc = (f32x16)(0.0f);
-    const char* gl = wlds + g * GROUP;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      if (steady) wait_vmcnt<TA * 16 - 4>(); else wait_vmcnt<0>();
+      // slabs c+1 .. c+NSLOT-1 were issued after this one iff the previous step issued
+      if (prev_issued) wait_vmcnt<4 * (NSLOT - 1)>(); else wait_vmcnt<0>();
+      const char* sl = wlds + slot * SLAB;
       f32x4 a[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) a[u] = *(const f32x4*)(gl + s * SLAB + rd[u]);
-      wait_lgkmcnt0();  // operands are in registers: the slab may be overwritten
-      if (steady) issue_slab(fbase, foff, g, s);
+      for (int u = 0; u < 4; ++u) a[u] = *(const f32x4*)(sl + rd[u]);
+      wait_lgkmcnt0();  // operands are in registers: the slot may be overwritten
+      const int fs = (s + NSLOT) & 3;
+      if (fs == 0 && F.valid) {
+        F.advance(p, qi);
+        if (F.valid) fetch_tile_setup();
+      }
+      if (F.valid) issue_slab(fs, slot);
+      prev_issued = F.valid;
+      slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         if (MODE == MODE_DENSE) a[u] *= mv;  // D * d_mask[..., None], BaseModel.py:41
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(a[u]));
+          continue;
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t)
           acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][t], qv[s * 4 + u][t], acc, 0, 0, 0);
@@ -329,10 +341,143 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_f32_h128(KARGS_DECL) {
       rmax = NEG_INF;
     }
     C.advance(p, qi);
-    if (steady) F.advance(p, qi);
-    g = (g + 1 == TA) ? 0 : g + 1;
   }
 
+  if (lane < jdoc) {
+    const int c = c_begin + wave + lane * WAVES;
+    p.scores[(int64_t)qi * p.ncand + c] = myscore;
+  }
+}
+
+// =============================================================================================
+// Tile-granular variant of the flagship kernel: a whole 32-token tile (16 KiB, CONTIGUOUS in HBM: 32
+// consecutive 512-B rows) is fetched by 16 LDS-DMA instructions of two full rows each, read into registers
+// in one go (64 VGPRs of A operands), and the next tile's fetch is issued into the same LDS buffer before
+// the 64 MFMAs start.  Every DMA instruction reads 1 KiB of consecutive addresses, so a tile is one
+// sequential 16-KiB burst (DRAM-page friendly) instead of four strided passes.
+// LDS image: row-major [32][512 B]; source chunk j of row m sits at chunk position j ^ (m & 15).
+// =============================================================================================
+template <int MODE, int WAVES, int NT, int ABLATE = 0>
+__global__ void __launch_bounds__(WAVES * 64) k_maxsim_f32_h128_t(KARGS_DECL) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KARGS_TO_PARAMS;
+  constexpr int ROWB = 512;
+  constexpr int TILE = 16384;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int qi = blockIdx.x / p.nchunk;
+  const int chunk = blockIdx.x - qi * p.nchunk;
+  const int c_begin = chunk * p.dpw;
+  const int c_end = min(p.ncand, c_begin + p.dpw);
+  char* const wlds = lds + wave * (NT * TILE);
+
+  const int n = lane & 31, kh = lane >> 5;
+  f32x4 qv[16];
+  {
+    int qlen = p.Lq;
+    if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
+    const bool live = n < qlen;
+    float qs = 1.0f;
+    if (MODE == MODE_DENSE && live && p.mask_dtype != MAXSIM_MASK_NONE)
+      qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + n);
+    const float* qrow = (const float*)p.Q + ((int64_t)qi * p.Lq + (live ? n : 0)) * 128 + 4 * kh;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      f32x4 v = *(const f32x4*)(qrow + 32 * (i >> 2) + 8 * (i & 3));
+      if (MODE == MODE_DENSE) v *= qs;
+      qv[i] = live ? v : (f32x4)(0.0f);
+    }
+  }
+
+  // DMA instruction i: lanes 0-31 -> row 2i, lanes 32-63 -> row 2i+1; chunk position lane & 31
+  const int dhalf = lane >> 5;
+  const int dchunk = lane & 31;
+  const int m = lane & 31;
+  const int rsw = m & 15;
+  const int rdbase = m * ROWB;
+
+  TileIt<MODE, WAVES> F, C;
+  F.init(p, qi, c_begin + wave, c_end);
+  C = F;
+  const char* const tok = (const char*)p.index;
+
+  auto issue_tile = [&](int buf) {
+    if (ABLATE == 2) return;
+    const char* base = tok + F.d.row0 * ROWB;
+    char* l = wlds + buf * TILE;
+    const int last = F.d.nfetch - 1;
+    const int r0 = F.t * 32 + dhalf;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int mm = 2 * i + dhalf;
+      const int r = min(r0 + 2 * i, last);
+      const uint32_t off = (uint32_t)r * ROWB + 16u * (uint32_t)(dchunk ^ (mm & 15));
+      __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
+    }
+  };
+
+  bool prev_issued = false;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    if (j > 0 && F.valid) F.advance(p, qi);
+    if (F.valid) issue_tile(j);
+    prev_issued = F.valid;
+  }
+
+  float rmax = NEG_INF;
+  float myscore = 0.0f;
+  int jdoc = 0;
+  int buf = 0;
+
+  while (C.valid) {
+    float mv = 1.0f;
+    if (MODE == MODE_DENSE && p.mask_dtype != MAXSIM_MASK_NONE) {
+      int r = min(C.t * 32 + m, C.d.nfetch - 1);
+      mv = load_mask(p.d_mask, p.mask_dtype, C.d.row0 + r);
+    }
+    if (prev_issued) wait_vmcnt<16 * (NT - 1)>(); else wait_vmcnt<0>();
+    const char* tl = wlds + buf * TILE + rdbase;
+    f32x4 a[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = *(const f32x4*)(tl + 16 * ((2 * i + kh) ^ rsw));
+    wait_lgkmcnt0();
+    if (F.valid) {
+      F.advance(p, qi);
+      if (F.valid) issue_tile(buf);
+    }
+    prev_issued = F.valid;
+    buf = (buf + 1 == NT) ? 0 : buf + 1;
+    f32x16 acc = (f32x16)(0.0f);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      if (MODE == MODE_DENSE) a[i] *= mv;
+      if (ABLATE == 1) {
+        asm volatile("" ::"v"(a[i]));
+        continue;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t], qv[i][t], acc, 0, 0, 0);
+    }
+    float t0 = fmaxf(fmaxf(acc[0], acc[1]), fmaxf(acc[2], acc[3]));
+    float t1 = fmaxf(fmaxf(acc[4], acc[5]), fmaxf(acc[6], acc[7]));
+    float t2 = fmaxf(fmaxf(acc[8], acc[9]), fmaxf(acc[10], acc[11]));
+    float t3 = fmaxf(fmaxf(acc[12], acc[13]), fmaxf(acc[14], acc[15]));
+    rmax = fmaxf(rmax, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+    if (C.t == C.ntile - 1) {
+      float v = fmaxf(rmax, __shfl_xor(rmax, 32));
+      if (C.d.floor0) v = fmaxf(v, 0.0f);
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 8);
+      v += __shfl_xor(v, 4);
+      v += __shfl_xor(v, 2);
+      v += __shfl_xor(v, 1);
+      float sc = C.d.kind == 0 ? v : (C.d.kind == 1 ? 0.0f : NEG_INF);
+      if (lane == jdoc) myscore = sc;
+      ++jdoc;
+      rmax = NEG_INF;
+    }
+    C.advance(p, qi);
+  }
   if (lane < jdoc) {
     const int c = c_begin + wave + lane * WAVES;
     p.scores[(int64_t)qi * p.ncand + c] = myscore;
@@ -471,17 +616,54 @@ int pick_dpw(int nq, int ncand, int waves) {
   return dpw;
 }
 
-template <int MODE>
-int launch_f32_h128(Params& p, hipStream_t st) {
-  constexpr int WAVES = 4, TA = 2;
+template <int MODE, int WAVES, int NSLOT, int ABLATE = 0>
+int launch_f32_h128_v(Params& p, hipStream_t st) {
   p.dpw = pick_dpw(p.nq, p.ncand, WAVES);
+  if (const char* e = getenv("MAXSIM_DPW")) p.dpw = atoi(e) > 0 ? atoi(e) * WAVES : p.dpw;
   p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
-  const int ldsb = WAVES * TA * 16384;
-  auto kern = k_maxsim_f32_h128<MODE, WAVES, TA>;
+  const int ldsb = WAVES * NSLOT * 4096;
+  auto kern = k_maxsim_f32_h128<MODE, WAVES, NSLOT, ABLATE>;
   int rc = allow_lds(kern, ldsb);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
   return check_launch();
+}
+
+template <int MODE, int WAVES, int NT, int ABLATE = 0>
+int launch_f32_h128_t(Params& p, hipStream_t st) {
+  p.dpw = pick_dpw(p.nq, p.ncand, WAVES);
+  if (const char* e = getenv("MAXSIM_DPW")) p.dpw = atoi(e) > 0 ? atoi(e) * WAVES : p.dpw;
+  p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+  const int ldsb = WAVES * NT * 16384;
+  auto kern = k_maxsim_f32_h128_t<MODE, WAVES, NT, ABLATE>;
+  int rc = allow_lds(kern, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  return check_launch();
+}
+
+template <int MODE>
+int launch_f32_h128(Params& p, hipStream_t st) {
+  int v = 0;
+  if (const char* e = getenv("MAXSIM_F32_VARIANT")) v = atoi(e);  // tuning knob
+  switch (v) {
+    case 1: return launch_f32_h128_v<MODE, 4, 3>(p, st);   // 48 KiB/WG: 3 WG/CU = 12 waves
+    case 2: return launch_f32_h128_v<MODE, 4, 5>(p, st);   // 80 KiB/WG: 2 WG/CU
+    case 3: return launch_f32_h128_v<MODE, 4, 8>(p, st);   // 128 KiB/WG: 1 WG/CU
+    case 4: return launch_f32_h128_v<MODE, 4, 2>(p, st);   // 32 KiB/WG: 5 WG/CU (VGPR-capped at 12 waves)
+    case 5: return launch_f32_h128_v<MODE, 6, 3>(p, st);   // 72 KiB/WG: 2 WG/CU = 12 waves
+    case 6: return launch_f32_h128_v<MODE, 8, 4>(p, st);   // 128 KiB/WG: 1 WG/CU = 8 waves
+    case 20: return launch_f32_h128_t<MODE, 4, 1>(p, st);     // tile-granular, 64 KiB/WG: 2 WG/CU = 8 waves
+    case 21: return launch_f32_h128_t<MODE, 4, 2>(p, st);     // 128 KiB/WG: 4 waves/CU, 2 tiles each
+    case 22: return launch_f32_h128_t<MODE, 2, 2>(p, st);     // 64 KiB/WG
+    case 23: return launch_f32_h128_t<MODE, 8, 1>(p, st);
+    case 24: return launch_f32_h128_t<MODE, 4, 1, 1>(p, st);  // ablation: no MFMA
+    case 25: return launch_f32_h128_t<MODE, 4, 1, 2>(p, st);  // ablation: no DMA
+    case 11: return launch_f32_h128_v<MODE, 4, 4, 1>(p, st);
+    case 12: return launch_f32_h128_v<MODE, 4, 4, 2>(p, st);
+    case 7: return launch_f32_h128_v<MODE, 4, 4>(p, st);   // slab ring, 64 KiB/WG: 2 WG/CU = 8 waves
+    default: return launch_f32_h128_t<MODE, 4, 1>(p, st);  // tile-granular, 64 KiB/WG: 2 WG/CU = 8 waves
+  }
 }
 
 template <int MODE>

@@ -27,6 +27,16 @@ def localize(cand_global, lo, hi):
     return torch.where(inr, cand_global - lo, torch.full_like(cand_global, -1)), inr
 
 
+def all_gather_topk(top_s, top_p, world, group=None):
+    """The path's ONE exchange step: every rank's [nq, k] scores and global pids -> [world, nq, k] on every rank."""
+    nq, k = top_s.shape
+    gs = torch.empty(world * nq, k, dtype=top_s.dtype, device=top_s.device)
+    gp = torch.empty(world * nq, k, dtype=top_p.dtype, device=top_p.device)
+    dist.all_gather_into_tensor(gs, top_s.contiguous(), group=group)
+    dist.all_gather_into_tensor(gp, top_p.contiguous(), group=group)
+    return gs.view(world, nq, k), gp.view(world, nq, k)
+
+
 def merge_gathered(all_scores, all_pids, k, topk_fn):
     """[world, nq, k] gathered local top-k -> global top-k per query."""
     world, nq, kk = all_scores.shape
@@ -57,8 +67,5 @@ class ShardedRanker:
         if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return top_p, top_s
         world = dist.get_world_size(self.group)
-        gs = torch.empty((world,) + tuple(top_s.shape), dtype=top_s.dtype, device=top_s.device)
-        gp = torch.empty((world,) + tuple(top_p.shape), dtype=top_p.dtype, device=top_p.device)
-        dist.all_gather_into_tensor(gs, top_s.contiguous(), group=self.group)
-        dist.all_gather_into_tensor(gp, top_p.contiguous(), group=self.group)
+        gs, gp = all_gather_topk(top_s, top_p, world, self.group)
         return merge_gathered(gs, gp, int(depth), self.topk_fn)

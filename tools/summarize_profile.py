@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 output merged back under gpurun_out/ into small tracked files under profiles/.
+
+    python tools/summarize_profile.py <tag> <trace_dir> [--fetch DIR] [--write DIR] [--sq DIR]
+
+Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, kernel names shortened),
+and profiles/<tag>_pmc.json (per-launch PMC values of the maxsim kernels).  HBM traffic follows
+MI355X_MICROARCH.md "HBM": FETCH_SIZE is in KiB-ish units of 1024 B and reports exactly 1/2 of the bytes of a
+wide coalesced 16-B/lane stream on gfx950, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE * 1024 is exact.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def short(name):
+    name = name.replace("(anonymous namespace)::", "")
+    return name if len(name) <= 90 else name[:87] + "..."
+
+
+def one(pattern):
+    f = glob.glob(pattern, recursive=True)
+    return f[0] if f else None
+
+
+def main():
+    tag, trace = sys.argv[1], sys.argv[2]
+    opts = dict(zip(sys.argv[3::2], sys.argv[4::2]))
+    os.makedirs("profiles", exist_ok=True)
+    ks = one(os.path.join(trace, "**", "*kernel_stats.csv"))
+    if ks:
+        rows = list(csv.DictReader(open(ks)))
+        with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
+            w = csv.writer(f)
+            w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
+            for r in rows[:12]:
+                w.writerow([short(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
+    out = {}
+    for key, flag in (("fetch", "--fetch"), ("write", "--write"), ("sq", "--sq")):
+        d = opts.get(flag)
+        if not d:
+            continue
+        cc = one(os.path.join(d, "**", "*counter_collection.csv"))
+        if not cc:
+            continue
+        for r in csv.DictReader(open(cc)):
+            if "maxsim" not in r["Kernel_Name"]:
+                continue
+            k = short(r["Kernel_Name"]).split("(")[0]
+            e = out.setdefault(k, {}).setdefault(r["Counter_Name"], [])
+            e.append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+                dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+                out[k].setdefault("dispatch_ns(sq pass)", []).append(dur)
+    summ = {}
+    for k, cs in out.items():
+        s = {c: sum(v) / len(v) for c, v in cs.items()}
+        s["launches_sampled"] = {c: len(v) for c, v in cs.items()}
+        if "FETCH_SIZE" in s:
+            s["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] = 2 * s["FETCH_SIZE"] * 1024
+        if "WRITE_SIZE" in s:
+            s["hbm_write_bytes_per_launch(WRITE_SIZE*1024)"] = s["WRITE_SIZE"] * 1024
+        if "GRBM_GUI_ACTIVE" in s and "dispatch_ns(sq pass)" in s:
+            s["effective_clock_GHz(GRBM_GUI_ACTIVE/8/ns)"] = s["GRBM_GUI_ACTIVE"] / 8 / s["dispatch_ns(sq pass)"]
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in s and "GRBM_GUI_ACTIVE" in s:
+            # busy cycles summed over 1024 SIMDs / (cycles per XCD-summed GUI_ACTIVE / 8)
+            s["mfma_util(SQ_VALU_MFMA_BUSY_CYCLES/1024 / (GRBM_GUI_ACTIVE/8))"] = (s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (s["GRBM_GUI_ACTIVE"] / 8)
+        summ[k] = s
+    with open(f"profiles/{tag}_pmc.json", "w") as f:
+        json.dump(summ, f, indent=1, sort_keys=True)
+    print(json.dumps(summ, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
