@@ -24,17 +24,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 LQ, LD, H, NQ, NCAND, TOPK = 32, 180, 128, 256, 1000, 100
+
+# extra workloads (reported next to the headline one, never as `value` of the default run):
+#   ragged : doclens ~ clipped N(120, 40) in [8, 180]     -- exercises packed tiles + 0-floor buckets
+#   c4     : multi-view, 8 viewer tokens per doc, Lq = 8 (dense.yaml q_view = d_view)
+#   c5     : bf16, dim 768, 256 tokens per doc, 200k docs
+WORKLOADS = {
+    "c2": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=False, dtype="fp32"),
+    "ragged": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=True, dtype="fp32"),
+    "c4": dict(lq=8, ld=8, h=128, ndocs=4_000_000, ragged=False, dtype="fp32"),
+    "c5": dict(lq=32, ld=256, h=768, ndocs=200_000, ragged=False, dtype="bf16"),
+}
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 
-def build_index(ndocs, dev, seed, dtype):
+def build_index(ntok, h, dev, seed, dtype):
     """F.normalize(randn) token embeddings, generated on-device in chunks (encoder output contract, BaseModel.py:26)."""
     gen = torch.Generator(device=dev).manual_seed(seed)
-    idx = torch.empty(ndocs * LD, H, dtype=dtype, device=dev)
-    chunk = 8192 * LD
-    for s in range(0, ndocs * LD, chunk):
-        e = min(s + chunk, ndocs * LD)
-        idx[s:e] = F.normalize(torch.randn(e - s, H, generator=gen, device=dev), dim=-1).to(dtype)
+    idx = torch.empty(ntok, h, dtype=dtype, device=dev)
+    chunk = max(1, (1 << 28) // h)
+    for s in range(0, ntok, chunk):
+        e = min(s + chunk, ntok)
+        idx[s:e] = F.normalize(torch.randn(e - s, h, generator=gen, device=dev), dim=-1).to(dtype)
     return idx
 
 
@@ -78,8 +89,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--ndocs", type=int, default=1_000_000, help="docs per GPU shard")
-    ap.add_argument("--index-dtype", default="fp32", choices=["fp32", "fp16", "bf16"])
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
+    ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
+    ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -95,19 +108,28 @@ def main():
     import colbert_amd
     from colbert_amd.sharded import ShardedRanker
 
+    wl = WORKLOADS[args.workload]
+    LQ, LD, H = (args.lq or wl["lq"]), wl["ld"], wl["h"]
+    args.index_dtype = args.index_dtype or wl["dtype"]
     dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.index_dtype]
     esize = torch.empty(0, dtype=dtype).element_size()
-    ndocs = args.ndocs
-    idx = build_index(ndocs, dev, 1234 + rank, dtype)
+    ndocs = args.ndocs or wl["ndocs"]
+    if wl["ragged"]:
+        g = torch.Generator().manual_seed(99 + rank)
+        doclens = (torch.randn(ndocs, generator=g) * 40 + 120).round().clamp(8, LD).long().tolist()
+    else:
+        # uniform docs: strides = [LD], one bucket, no padding floor
+        doclens = [LD] * ndocs
+    ntok = sum(doclens)
+    idx = build_index(ntok, H, dev, 1234 + rank, dtype)
     ranker = colbert_amd.ColbertRanker.__new__(colbert_amd.ColbertRanker)
-    # uniform 180-token docs: strides = [180], one bucket, no padding floor
     ranker.maxsim_dtype = torch.float32
     ranker.device = dev
     ranker.model = None
     ranker.pid_offset = rank * ndocs
     ranker.tensor = idx
-    ranker.num_embeddings = ndocs * LD
-    ranker.init_ranker([LD] * ndocs)
+    ranker.num_embeddings = ntok
+    ranker.init_ranker(doclens)
     lo, hi = rank * ndocs, (rank + 1) * ndocs
     sharded = ShardedRanker(ranker, lo, hi)
 
@@ -156,14 +178,15 @@ def main():
     kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(args.warmup, total)) / args.steps
     # algorithmic bytes of ONE rerank launch on this rank: doc tokens read once + Q + pid/offset/len + score
     docs = nq * per
-    alg_bytes = docs * LD * H * esize + nq * LQ * H * 4 + docs * (8 + 12 + 4)
+    cand_tokens = int(ranker.d_doclens[(cands[args.warmup:] - lo).reshape(-1)].sum().item()) / args.steps
+    alg_bytes = int(cand_tokens * H * esize + nq * LQ * H * 4 + docs * (8 + 12 + 4))
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
     # MI355X_MICROARCH.md prescribes; summary committed under profiles/ by tools/summarize_profile.py)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", f"r01_c2_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
-    if world == 1 and ndocs == 1_000_000 and os.path.exists(pmc):
+    if world == 1 and args.workload == "c2" and ndocs == 1_000_000 and os.path.exists(pmc):
         try:
             for k, v in json.load(open(pmc)).items():
                 if "maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
@@ -173,20 +196,22 @@ def main():
 
     if rank == 0:
         res = {
-            "metric": "queries/sec MaxSim rerank, 32q x 180d tokens, dim=128, 1000 docs/query",
+            "metric": "queries/sec MaxSim rerank, 32q x 180d tokens, dim=128, 1000 docs/query" if args.workload == "c2"
+                      else f"queries/sec MaxSim rerank, workload {args.workload}",
             "value": round(nq * args.steps / el, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"C2: {NQ} queries/GPU x {NCAND} candidates/query, {LQ}x{LD} tokens, dim {H}, "
+            "config": {"workload": f"{args.workload.upper()}: {NQ} queries/GPU x {NCAND} candidates/query, {LQ}x"
+                                   f"{'~120 (8..180 ragged)' if wl['ragged'] else LD} tokens, dim {H}, "
                                    f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}",
                        "queries_per_step": nq, "candidates_per_query": NCAND, "docs_per_gpu": ndocs,
                        "index_dtype": args.index_dtype, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_maxsim_*_h128 (rerank)", "kernel_ms": round(kern_ms, 4),
+                         "kernel": "k_maxsim_stream (rerank)" if H == 128 and LQ <= 32 else "k_maxsim_generic (rerank)", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
     if world > 1:

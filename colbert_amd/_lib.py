@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmaxsim.so")
+LIB_PATH = os.environ.get("MAXSIM_LIB", os.path.join(_HERE, "libmaxsim.so"))  # MAXSIM_LIB: A/B builds
 
 # include/maxsim.h
 F32, F16, BF16 = 0, 1, 2

@@ -5,4 +5,4 @@ HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 "$HIPCC" -O3 --offload-arch=gfx950 -std=c++17 -I"$ROOT/include" -shared -fPIC \
-    "$HERE/maxsim.hip" -o "$ROOT/colbert_amd/libmaxsim.so" "$@"
+    -I"$HERE" "$HERE/maxsim.hip" -o "$ROOT/colbert_amd/libmaxsim.so" "$@"

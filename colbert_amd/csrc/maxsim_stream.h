@@ -1,0 +1,413 @@
+// maxsim_stream.h -- the MFMA streaming kernel of libmaxsim: h = 128, Lq <= 32, fp32 / fp16 / bf16 token matrix.
+//
+// One wave64 = one independent TOKEN STREAM: the tokens of the wave's candidate docs laid end to end.  The stream
+// is cut into 32-row tiles that may straddle document boundaries ("packed tiles": no MFMA work is spent on
+// padding except in the wave's very last tile).  Per tile:
+//   fetch    NDMA LDS-DMA instructions (global_load_lds_dwordx4, 1 KiB each = whole token rows; a tile that lies
+//            inside one doc is one contiguous burst addressed SGPR-base + lane offset; a tile that crosses docs
+//            takes each row's address from the lane that owns the slot via ds_bpermute) into the wave's private
+//            LDS ring of NT tiles.  Source chunk j of row slot m is stored at chunk position j ^ (m & 15): the
+//            LDS-DMA destination stays linear (it must), the ds_read_b128 operand reads are bank-conflict free.
+//   compute  the whole tile goes to registers (A operands), the NEXT tile's fetch is issued into the freed
+//            buffer, then the contraction runs on MFMA with fp32 accumulation:
+//              fp32 index: v_mfma_f32_32x32x2_f32 -- an exact k-ordered fp32 fmaf chain (bitwise reproducible);
+//              fp16 index: v_mfma_f32_32x32x16_f16, Q = Qhi + 2^-11 Qlo (two accumulators);
+//              bf16 index: v_mfma_f32_32x32x16_bf16, Q = Q0 + Q1 + Q2.
+//            A = doc tokens (rows), B = query tokens (columns): a lane's 16 accumulators are 16 doc tokens of ONE
+//            query token, so max-over-doc-tokens is in-lane + one exchange between the lane halves.
+//   reduce   per document segment of the tile: (masked) max into the doc's running max; when a doc ends:
+//            halves exchange, 0-floor, DPP pairwise-tree sum over query tokens, score kept in lane (doc ordinal).
+// There is no workgroup barrier: waves pace their own ring with counted s_waitcnt vmcnt.
+#pragma once
+#include "maxsim_common.h"
+
+namespace maxsim {
+
+template <int DT>
+struct StreamTraits;
+template <>
+struct StreamTraits<MAXSIM_F32> {
+  static constexpr int ROWB = 512, TILE = 16384, NDMA = 16, RPD = 2, LPR = 32, NRD = 16, NP = 1;
+};
+template <>
+struct StreamTraits<MAXSIM_F16> {
+  static constexpr int ROWB = 256, TILE = 8192, NDMA = 8, RPD = 4, LPR = 16, NRD = 8, NP = 2;
+};
+template <>
+struct StreamTraits<MAXSIM_BF16> {
+  static constexpr int ROWB = 256, TILE = 8192, NDMA = 8, RPD = 4, LPR = 16, NRD = 8, NP = 3;
+};
+
+// The wave's candidate docs are described ONCE, up front, in "descriptor lanes": lane j holds the first token row,
+// the length and the flags of the wave's j-th doc (at most 64 docs per wave), gathered with ordinary vector loads
+// before the LDS-DMA stream starts.  Walking the docs afterwards is three v_readlane per doc: no memory access, hence
+// no load latency (and no vmcnt/lgkmcnt traffic) inside the streaming loop.
+struct DocLanes {
+  uint32_t row0;  // first token row
+  int len;        // tokens to score (0: empty doc or padding slot)
+  int flags;      // kind (bits 0-1: 0 scored, 1 empty doc -> 0, 2 padding slot -> -inf) | floor0 << 2
+};
+
+template <int MODE>
+__device__ __forceinline__ DocLanes load_doc_lanes(const Params& p, int qi, int c0, int ndoc, int lane) {
+  DocLanes d;
+  d.row0 = 0; d.len = 0; d.flags = 2;
+  if (lane < ndoc) {
+    const int c = c0 + lane;
+    if constexpr (MODE == MODE_DENSE) {
+      d.row0 = (uint32_t)((int64_t)c * p.Ld);
+      d.len = p.Ld;
+      d.flags = 0;
+    } else {
+      const int64_t pid = p.cand[(int64_t)qi * p.ncand + c];
+      bool ok = pid >= 0 && pid < p.n_docs;
+      const int64_t safe = ok ? pid : 0;
+      const int64_t off = p.tok_offsets[safe];
+      const int len = p.doclens[safe];
+      const int pad = p.pad_len ? p.pad_len[safe] : len;
+      ok = ok && off >= 0 && len >= 0 && off + len <= p.n_tokens;  // defensive: never stream outside the matrix
+      const int kind = !ok ? 2 : (len == 0 ? 1 : 0);
+      d.row0 = kind == 0 ? (uint32_t)off : 0u;
+      d.len = kind == 0 ? len : 0;
+      d.flags = kind | ((pad > len) ? 4 : 0);
+    }
+  }
+  return d;
+}
+
+// Wave-uniform cursor over the wave's docs.
+struct Cursor {
+  int j, ndoc, pos, len, kind, floor0;
+  uint32_t row0;
+  bool valid;
+  // (all fields are assigned unconditionally: conditional stores to different fields get merged by the optimizer
+  //  into a store through a selected pointer, which pins the whole cursor in scratch memory)
+  __device__ __forceinline__ void load(const DocLanes& d) {
+    valid = j < ndoc;
+    const int jj = valid ? j : 0;
+    const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)d.row0, jj);
+    const int ln = __builtin_amdgcn_readlane(d.len, jj);
+    const int fl = __builtin_amdgcn_readlane(d.flags, jj);
+    row0 = valid ? r0 : 0u;
+    len = valid ? ln : 0;
+    kind = valid ? (fl & 3) : 2;
+    floor0 = valid ? (fl >> 2) : 0;
+    pos = 0;
+  }
+  __device__ __forceinline__ void init(const DocLanes& d, int nd) {
+    j = 0;
+    ndoc = nd;
+    load(d);
+  }
+  __device__ __forceinline__ void next_doc(const DocLanes& d) {
+    ++j;
+    load(d);
+  }
+};
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {  // v as seen through the DPP lane permutation CTRL (all lanes on)
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+
+// Lays the next 32 stream rows onto the tile's row slots.  `myrow` = token-matrix row of slot (lane & 31).
+// Returns the number of real rows (0: stream exhausted).  Slots past the stream end repeat the last real row
+// (a duplicate cannot change a max).  `single`: the tile is 32 consecutive rows of one doc starting at row_first.
+__device__ __forceinline__ int fill_tile(Cursor& F, const DocLanes& dl, int r, uint32_t& myrow, bool& single,
+                                         uint32_t& row_first) {
+  int filled = 0;
+  uint32_t last = 0;
+  single = false;
+  row_first = 0;
+  myrow = 0;
+  while (filled < 32 && F.valid) {
+    const int take = uni(min(32 - filled, max(F.len - F.pos, 0)));  // 0: empty doc / padding slot, just skipped
+    const uint32_t base = F.row0 + (uint32_t)F.pos - (uint32_t)filled;  // slot r -> row base + r
+    if (filled == 0 && take > 0) {
+      row_first = base;
+      single = (take == 32);
+    }
+    const bool in = (r >= filled) & (r < filled + take);
+    myrow = in ? base + (uint32_t)r : myrow;
+    if (take > 0) last = base + (uint32_t)(filled + take - 1);
+    filled += take;
+    F.pos += take;
+    if (F.pos >= F.len) F.next_doc(dl);
+  }
+  if (filled > 0 && filled < 32) myrow = (r >= filled) ? last : myrow;
+  return filled;
+}
+
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
+__global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
+  static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is fp32 only");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KARGS_TO_PARAMS;
+  using T = StreamTraits<DT>;
+  constexpr int ROWB = T::ROWB, TILE = T::TILE, NDMA = T::NDMA, RPD = T::RPD, LPR = T::LPR, NRD = T::NRD, NP = T::NP;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int qi = blockIdx.x / p.nchunk;
+  const int chunk = blockIdx.x - qi * p.nchunk;
+  const int dpwv = p.dpw / WAVES;                 // docs per wave (<= 64)
+  const int c_begin = chunk * p.dpw + wave * dpwv;  // this wave's candidates: [c_begin, c_begin + ndoc)
+  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  const DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
+  char* const wlds = lds + wave * (NT * TILE);
+  const int r = lane & 31, hh = lane >> 5;
+
+  // ---- query tile -> registers in MFMA B layout --------------------------------------------------------------
+  // fp32: lane (n, hh) holds Q[n][32 s + 8 u + 4 hh + t]   in qv[4 s + u][t]
+  // 16b : lane (n, hh) holds Q[n][16 i + 8 hh + j], j=0..7 in qp[piece][i] (packed pairs)
+  f32x4 qv[DT == MAXSIM_F32 ? 16 : 1];
+  u32x4 qp[DT == MAXSIM_F32 ? 1 : NP][DT == MAXSIM_F32 ? 1 : 8];
+  {
+    int qlen = p.Lq;
+    if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
+    const bool live = r < qlen;
+    const float* qrow = (const float*)p.Q + ((int64_t)qi * p.Lq + (live ? r : 0)) * 128;
+    if constexpr (DT == MAXSIM_F32) {
+      float qs = 1.0f;
+      if (MODE == MODE_DENSE && live && p.mask_dtype != MAXSIM_MASK_NONE)
+        qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + r);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        f32x4 v = *(const f32x4*)(qrow + 4 * hh + 32 * (i >> 2) + 8 * (i & 3));
+        if (MODE == MODE_DENSE) v *= qs;  // Q * q_mask[..., None], BaseModel.py:42
+        qv[i] = live ? v : (f32x4)(0.0f);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        f32x4 v0 = *(const f32x4*)(qrow + 8 * hh + 16 * i);
+        f32x4 v1 = *(const f32x4*)(qrow + 8 * hh + 16 * i + 4);
+        float q[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        uint16_t pc[NP][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = live ? q[j] : 0.0f;
+          if constexpr (DT == MAXSIM_F16) {
+            _Float16 hi = (_Float16)x;
+            _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+            __builtin_memcpy(&pc[0][j], &hi, 2);
+            __builtin_memcpy(&pc[1][j], &lo, 2);
+          } else {
+            uint16_t b0 = f32_to_bf16_rn(x);
+            float r1 = x - bf16_to_f32(b0);
+            uint16_t b1 = f32_to_bf16_rn(r1);
+            float r2 = r1 - bf16_to_f32(b1);
+            pc[0][j] = b0;
+            pc[1][j] = b1;
+            pc[NP - 1][j] = f32_to_bf16_rn(r2);
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+#pragma unroll
+          for (int w = 0; w < 4; ++w) qp[k][i][w] = (uint32_t)pc[k][2 * w] | ((uint32_t)pc[k][2 * w + 1] << 16);
+      }
+    }
+  }
+
+  // ---- per-lane constants ------------------------------------------------------------------------------------
+  const int dslot0 = lane / LPR;  // DMA instruction i covers row slots RPD * i + dslot0
+  const int dchunk = lane % LPR;  // 16-byte chunk position inside the row
+  const int rsw = r & 15;
+  const int rdbase = r * ROWB;
+  const char* const tok = (const char*)p.index;
+
+  Cursor F, C;
+  F.init(dl, ndoc);
+  C = F;
+
+  auto issue_tile = [&](int buf, uint32_t myrow, bool single, uint32_t row_first) __attribute__((always_inline)) {
+    if (ABLATE == 2) return;
+    char* l = wlds + buf * TILE;
+    // (the lane constants are made opaque here so that hipcc recomputes the 2-3 VALU ops per instruction instead
+    //  of keeping NDMA loop-invariant offsets alive in VGPRs across the whole tile loop)
+    int ds0 = dslot0, dch = dchunk;
+    asm volatile("" : "+v"(ds0), "+v"(dch));
+    if (single) {  // one contiguous burst: uniform base in SGPRs + per-lane 32-bit offset
+      const char* base = tok + (uint64_t)row_first * ROWB;
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int slot = RPD * i + ds0;
+        const uint32_t off = (uint32_t)slot * ROWB + 16u * (uint32_t)(dch ^ (slot & 15));
+        __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
+      }
+    } else {  // rows of several docs: each slot's row comes from the lane that owns the slot
+#pragma unroll 2
+      for (int i = 0; i < NDMA; ++i) {
+        const int slot = RPD * i + ds0;
+        const uint32_t row = (uint32_t)__shfl((int)myrow, slot);
+        const char* g = tok + (uint64_t)row * ROWB + 16u * (uint32_t)(dch ^ (slot & 15));
+        __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  // ---- prologue: up to NT tiles in flight -----------------------------------------------------------------------
+  int nissued = 0, nconsumed = 0;
+  bool prev_issued = false;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    uint32_t myrow, row_first;
+    bool single;
+    const int filled = fill_tile(F, dl, r, myrow, single, row_first);
+    if (filled > 0) {
+      issue_tile(j, myrow, single, row_first);
+      ++nissued;
+    }
+    prev_issued = filled > 0;
+  }
+
+  float rmax = NEG_INF;
+  float myscore = 0.0f;
+  int jdoc = 0;
+  int buf = 0;
+
+  // A finished doc: exchange the lane halves (v_permlane32_swap), 0-floor, then sum the 32 query-token lanes with
+  // DPP adds -- a pairwise tree ((q0+q1)+(q2+q3))+... in VALU registers, no LDS round trips (a ds_bpermute
+  // butterfly costs ~6 dependent LDS latencies per doc, which dominates when docs are a few tokens long).
+  auto finalize = [&]() __attribute__((always_inline)) {  // C's current doc is complete
+    float sc;
+    if (C.kind == 0) {
+      const uint32_t xb = __float_as_uint(rmax);
+      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+      float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      if (C.floor0) v = fmaxf(v, 0.0f);
+      v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+      v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+      v += dpp_f32<0x141>(v);  // row_half_mirror: 8-lane sums
+      v += dpp_f32<0x140>(v);  // row_mirror: 16-lane sums
+      // rows 0 and 1 hold the two halves of the 32 query tokens (rows 2, 3 mirror them)
+      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+           __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    } else {
+      sc = C.kind == 1 ? 0.0f : NEG_INF;
+    }
+    if (lane == jdoc) myscore = sc;
+    ++jdoc;
+    rmax = NEG_INF;
+  };
+
+  while (nconsumed < nissued) {
+    // tiles c+1 .. c+NT-1 were issued after this one iff the previous step issued
+    if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
+    const char* tl = wlds + buf * TILE + rdbase;
+    u32x4 a[NRD];
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) a[i] = *(const u32x4*)(tl + 16 * ((2 * i + hh) ^ rsw));
+    wait_lgkmcnt0();  // operands are in registers: the buffer may be overwritten
+    {
+      uint32_t myrow, row_first;
+      bool single;
+      const int filled = fill_tile(F, dl, r, myrow, single, row_first);
+      if (filled > 0) {
+        issue_tile(buf, myrow, single, row_first);
+        ++nissued;
+      }
+      prev_issued = filled > 0;
+    }
+    buf = (buf + 1 == NT) ? 0 : buf + 1;
+
+    float mv = 1.0f;
+    if constexpr (MODE == MODE_DENSE) {  // D * d_mask[..., None], BaseModel.py:41
+      if (p.mask_dtype != MAXSIM_MASK_NONE) {
+        Cursor Cp = C;
+        uint32_t crow, rf;
+        bool sg;
+        fill_tile(Cp, dl, r, crow, sg, rf);
+        mv = load_mask(p.d_mask, p.mask_dtype, (int64_t)crow);
+      }
+    }
+
+    float sv[16];
+    if constexpr (DT == MAXSIM_F32) {
+      f32x16 acc = (f32x16)(0.0f);
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        f32x4 av = __builtin_bit_cast(f32x4, a[i]);
+        if (MODE == MODE_DENSE) av *= mv;
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(av));
+          continue;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], qv[i][t], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sv[v] = acc[v];
+    } else {
+      f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(a[i]));
+          continue;
+        }
+        if constexpr (DT == MAXSIM_F16) {
+          const f16x8 av = __builtin_bit_cast(f16x8, a[i]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, qp[0][i]), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, __builtin_bit_cast(f16x8, qp[1][i]), acc1, 0, 0, 0);
+        } else {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, qp[0][i]), acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, qp[1][i]), acc1, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, __builtin_bit_cast(bf16x8, qp[NP - 1][i]), acc1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v)
+        sv[v] = (DT == MAXSIM_F16) ? fmaf(acc1[v], 1.0f / 2048.0f, acc0[v]) : (acc0[v] + acc1[v]);
+    }
+
+    // ---- reduce: walk the document segments of this tile ---------------------------------------------------
+    int filled = 0;
+    while (filled < 32 && C.valid) {
+      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));  // 0: empty doc / padding slot
+      if (take == 32) {
+        float t0 = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        float t1 = fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7]));
+        float t2 = fmaxf(fmaxf(sv[8], sv[9]), fmaxf(sv[10], sv[11]));
+        float t3 = fmaxf(fmaxf(sv[12], sv[13]), fmaxf(sv[14], sv[15]));
+        rmax = fmaxf(rmax, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+      } else if (take > 0 && ((filled | take) & 7) == 0) {
+        // segment made of whole 8-row groups (e.g. the 8-token multi-view docs): group g = rows 8g..8g+7 is exactly
+        // accumulators 4g..4g+3 of both lane halves -> no per-row masking, wave-uniform group selection
+        float m = NEG_INF;
+        const int g0 = filled >> 3, g1 = (filled + take) >> 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float mg = fmaxf(fmaxf(sv[4 * g], sv[4 * g + 1]), fmaxf(sv[4 * g + 2], sv[4 * g + 3]));
+          m = (g >= g0 && g < g1) ? fmaxf(m, mg) : m;
+        }
+        rmax = fmaxf(rmax, m);
+      } else if (take > 0) {  // rows [filled, filled + take) only; accumulator v of this lane is row (v&3) + 8 (v>>2) + 4 hh
+        float m = NEG_INF;
+        const uint32_t lo = (uint32_t)(filled - 4 * hh), n_in = (uint32_t)take;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const uint32_t rel = (uint32_t)((v & 3) + 8 * (v >> 2)) - lo;
+          m = fmaxf(m, rel < n_in ? sv[v] : NEG_INF);
+        }
+        rmax = fmaxf(rmax, m);
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {  // doc complete (empty docs / padding slots are scored on the spot)
+        finalize();
+        C.next_doc(dl);
+      }
+    }
+    ++nconsumed;
+  }
+  while (C.valid) {  // trailing empty docs / padding slots
+    finalize();
+    C.next_doc(dl);
+  }
+
+  if (lane < jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = myscore;
+}
+
+}  // namespace maxsim
