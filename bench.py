@@ -185,8 +185,8 @@ def main():
     # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
     # MI355X_MICROARCH.md prescribes; summary committed under profiles/ by tools/summarize_profile.py)
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", f"r01_c2_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
-    if world == 1 and args.workload == "c2" and ndocs == 1_000_000 and os.path.exists(pmc):
+    pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
+    if world == 1 and ndocs == wl["ndocs"] and not args.lq and os.path.exists(pmc):
         try:
             for k, v in json.load(open(pmc)).items():
                 if "maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
@@ -208,7 +208,7 @@ def main():
                        "index_dtype": args.index_dtype, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_maxsim_stream (rerank)" if H == 128 and LQ <= 32 else "k_maxsim_generic (rerank)", "kernel_ms": round(kern_ms, 4),
+                         "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":

@@ -40,7 +40,7 @@ def _load():
     lib.maxsim_score_dense.restype = i32
     lib.maxsim_score_dense.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.maxsim_rerank.restype = i32
-    lib.maxsim_rerank.argtypes = [vp, i32, i64, vp, vp, vp, i64, vp, vp, vp, i32, i32, i32, i32, vp, vp]
+    lib.maxsim_rerank.argtypes = [vp, i32, i64, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.maxsim_topk.restype = i32
     lib.maxsim_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
     return lib

@@ -9,6 +9,7 @@
 #include "maxsim_common.h"
 #include "maxsim_generic.h"
 #include "maxsim_stream.h"
+#include "maxsim_stream_bigh.h"
 #include "maxsim_topk.h"
 
 using namespace maxsim;
@@ -69,6 +70,40 @@ int launch_stream(Params& p, hipStream_t st) {
   }
 }
 
+// Wide embeddings (h = 128 * KB): query image in LDS (NPQ x KB x sub-tile bytes), the rest of the 160 KiB goes to the
+// waves' rings: as many waves (<= 8) as fit with NT sub-tiles each.
+template <int DT, int NPQ>
+int launch_stream_bigh(Params& p, hipStream_t st) {
+  constexpr int SUB = StreamTraits<DT>::TILE;
+  const int KB = p.h / 128;
+  const int qbytes = NPQ * KB * SUB;
+  const int avail = 160 * 1024 - qbytes;
+  int dpwv = env_int("MAXSIM_DPW", 0);
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4) ;
+  auto go = [&](auto kern, int waves, int nt) {
+    p.dpw = dpwv * waves;
+    p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+    const int ldsb = qbytes + waves * nt * SUB;
+    int rc = allow_lds(kern, ldsb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
+    return check_launch();
+  };
+  if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<DT, NPQ, 8, 2>, 8, 2);
+  if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<DT, NPQ, 4, 2>, 4, 2);
+  if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<DT, NPQ, 4, 1>, 4, 1);
+  return MAXSIM_ERANGE;
+}
+
+int launch_bigh(Params& p, int dt, hipStream_t st) {
+  const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;  // query already in the index's 16-bit type: one piece
+  switch (dt) {
+    case MAXSIM_F32: return launch_stream_bigh<MAXSIM_F32, 1>(p, st);
+    case MAXSIM_F16: return same16 ? launch_stream_bigh<MAXSIM_F16, 1>(p, st) : launch_stream_bigh<MAXSIM_F16, 2>(p, st);
+    default: return same16 ? launch_stream_bigh<MAXSIM_BF16, 1>(p, st) : launch_stream_bigh<MAXSIM_BF16, 2>(p, st);
+  }
+}
+
 template <int MODE>
 int launch_generic(Params& p, int dt, hipStream_t st) {
   const dim3 grid((unsigned)((int64_t)p.nq * p.ncand)), block(256);
@@ -124,6 +159,7 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
   p.n_tokens = (int64_t)nd * Ld;
   p.n_docs = nd;
   p.Q = Q;
+  p.q_dtype = dtype;
   p.nq = nq; p.ncand = nd; p.Lq = Lq; p.h = h;
   p.scores = out;
   p.q_mask = q_mask; p.d_mask = d_mask; p.mask_dtype = mask_dtype;
@@ -134,11 +170,12 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
 }
 
 int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,
-                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const float* Q,
+                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const void* Q, int q_dtype,
                   const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
                   float* scores, void* stream) {
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
   if (index_dtype < MAXSIM_F32 || index_dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
+  if (q_dtype < MAXSIM_F32 || q_dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
   if (ncand == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
   if (nq == 0) return MAXSIM_OK;
   if (!scores || !cand_pids || !tok_offsets || !doclens || !Q) return MAXSIM_EINVAL;
@@ -153,6 +190,7 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
   p.pad_len = pad_len;
   p.n_docs = n_docs;
   p.Q = Q;
+  p.q_dtype = q_dtype;
   p.q_len = q_len;
   p.cand = cand_pids;
   p.nq = nq; p.ncand = ncand; p.Lq = Lq; p.h = h;
@@ -162,6 +200,10 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
     if (index_dtype == MAXSIM_F32) return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
     if (index_dtype == MAXSIM_F16) return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
     return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
+  }
+  if (h > 128 && h <= 1024 && (h & 127) == 0 && Lq >= 1 && Lq <= 32 && n_tokens > 0 && n_tokens <= 0xffffffffLL) {
+    int rc = launch_bigh(p, index_dtype, st);
+    if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_RERANK>(p, index_dtype, st);
 }

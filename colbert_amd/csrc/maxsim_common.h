@@ -31,6 +31,7 @@ struct Params {
   int64_t n_docs;
   // queries
   const void* Q;
+  int q_dtype;  // element type of Q (rerank: MAXSIM_F32 / F16 / BF16; dense: same as the token matrix)
   const int32_t* q_len;
   const int64_t* cand;
   int nq, ncand, Lq, h;
@@ -51,7 +52,7 @@ struct Params {
 // stream and drain it at every document boundary.
 struct Scalars {
   int64_t n_tokens, n_docs;
-  int nq, ncand, Lq, h, mask_dtype, Ld, dpw, nchunk;
+  int nq, ncand, Lq, h, mask_dtype, Ld, dpw, nchunk, q_dtype;
 };
 #define KARGS_DECL                                                                                         \
   const void* __restrict__ a_index, const int64_t* __restrict__ a_tok_offsets,                              \
@@ -64,11 +65,12 @@ struct Scalars {
   p.index = a_index; p.n_tokens = sc.n_tokens; p.tok_offsets = a_tok_offsets; p.doclens = a_doclens;        \
   p.pad_len = a_pad_len; p.n_docs = sc.n_docs; p.Q = a_Q; p.q_len = a_q_len; p.cand = a_cand;               \
   p.nq = sc.nq; p.ncand = sc.ncand; p.Lq = sc.Lq; p.h = sc.h; p.scores = a_scores; p.q_mask = a_q_mask;     \
-  p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk
+  p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk;         \
+  p.q_dtype = sc.q_dtype
 #define KARGS_PASS(p)                                                                                       \
   (p).index, (p).tok_offsets, (p).doclens, (p).pad_len, (p).Q, (p).q_len, (p).cand, (p).scores, (p).q_mask, \
       (p).d_mask, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
-                                    (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk }
+                                    (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -103,6 +105,13 @@ __device__ __forceinline__ uint16_t f32_to_bf16_rn(float f) {  // finite inputs 
   uint32_t u = __float_as_uint(f);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float load_q(const void* Q, int q_dtype, int64_t i) {
+  switch (q_dtype) {
+    case MAXSIM_F16: return f16_to_f32(((const uint16_t*)Q)[i]);
+    case MAXSIM_BF16: return bf16_to_f32(((const uint16_t*)Q)[i]);
+    default: return ((const float*)Q)[i];
+  }
 }
 template <int DT>
 __device__ __forceinline__ float load_elem(const void* p, int64_t i) {

@@ -36,7 +36,7 @@ __global__ void __launch_bounds__(256) k_maxsim_generic(KARGS_DECL) {
         const int64_t dbase = (d.row0 + nn) * h;
         float acc = 0.0f;
         for (int k = 0; k < h; ++k) {
-          float qv = (MODE == MODE_DENSE ? load_elem<DT>(p.Q, qbase + k) : ((const float*)p.Q)[qbase + k]);
+          float qv = load_q(p.Q, p.q_dtype, qbase + k);
           float dv = load_elem<DT>(p.index, dbase + k);
           if (masked) { qv *= qs; dv *= ds; }
           acc = fmaf(qv, dv, acc);

@@ -138,6 +138,90 @@ __device__ __forceinline__ int fill_tile(Cursor& F, const DocLanes& dl, int r, u
   return filled;
 }
 
+// Per-wave reduction state: running max of the current doc (per lane: one query token, one lane half) and the
+// finished docs' scores parked one per lane.
+struct Reducer {
+  float rmax, myscore;
+  int jdoc;
+  __device__ __forceinline__ void init() {
+    rmax = NEG_INF;
+    myscore = 0.0f;
+    jdoc = 0;
+  }
+  // C's current doc is complete: exchange the lane halves (v_permlane32_swap), 0-floor, then sum the 32 query-token
+  // lanes with DPP adds -- a pairwise tree ((q0+q1)+(q2+q3))+... in VALU registers, no LDS round trips (a
+  // ds_bpermute butterfly costs ~6 dependent LDS latencies per doc, which dominates when docs are a few tokens long).
+  __device__ __forceinline__ void finish_doc(const Cursor& C, int lane) {
+    float sc;
+    if (C.kind == 0) {
+      const uint32_t xb = __float_as_uint(rmax);
+      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+      float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      if (C.floor0) v = fmaxf(v, 0.0f);
+      v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+      v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+      v += dpp_f32<0x141>(v);  // row_half_mirror: 8-lane sums
+      v += dpp_f32<0x140>(v);  // row_mirror: 16-lane sums
+      // rows 0 and 1 hold the two halves of the 32 query tokens (rows 2, 3 mirror them)
+      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+           __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    } else {
+      sc = C.kind == 1 ? 0.0f : NEG_INF;
+    }
+    myscore = (lane == jdoc) ? sc : myscore;
+    ++jdoc;
+    rmax = NEG_INF;
+  }
+  // Walks the document segments of one finished tile.  sv[v] = similarity of this lane's query token with tile row
+  // (v & 3) + 8 (v >> 2) + 4 (lane >> 5).
+  __device__ __forceinline__ void reduce_tile(const float (&sv)[16], Cursor& C, const DocLanes& dl, int lane) {
+    const int hh = lane >> 5;
+    int filled = 0;
+    while (filled < 32 && C.valid) {
+      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));  // 0: empty doc / padding slot
+      if (take == 32) {
+        float t0 = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        float t1 = fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7]));
+        float t2 = fmaxf(fmaxf(sv[8], sv[9]), fmaxf(sv[10], sv[11]));
+        float t3 = fmaxf(fmaxf(sv[12], sv[13]), fmaxf(sv[14], sv[15]));
+        rmax = fmaxf(rmax, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+      } else if (take > 0 && ((filled | take) & 7) == 0) {
+        // segment made of whole 8-row groups (e.g. the 8-token multi-view docs): group g = rows 8g..8g+7 is exactly
+        // accumulators 4g..4g+3 of both lane halves -> no per-row masking, wave-uniform group selection
+        float m = NEG_INF;
+        const int g0 = filled >> 3, g1 = (filled + take) >> 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const float mg = fmaxf(fmaxf(sv[4 * g], sv[4 * g + 1]), fmaxf(sv[4 * g + 2], sv[4 * g + 3]));
+          m = (g >= g0 && g < g1) ? fmaxf(m, mg) : m;
+        }
+        rmax = fmaxf(rmax, m);
+      } else if (take > 0) {  // rows [filled, filled + take) only
+        float m = NEG_INF;
+        const uint32_t lo = (uint32_t)(filled - 4 * hh), n_in = (uint32_t)take;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const uint32_t rel = (uint32_t)((v & 3) + 8 * (v >> 2)) - lo;
+          m = fmaxf(m, rel < n_in ? sv[v] : NEG_INF);
+        }
+        rmax = fmaxf(rmax, m);
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {  // doc complete (empty docs / padding slots are scored on the spot)
+        finish_doc(C, lane);
+        C.next_doc(dl);
+      }
+    }
+  }
+  __device__ __forceinline__ void drain(Cursor& C, const DocLanes& dl, int lane) {  // trailing empty docs / padding
+    while (C.valid) {
+      finish_doc(C, lane);
+      C.next_doc(dl);
+    }
+  }
+};
+
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is fp32 only");
@@ -165,23 +249,39 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     int qlen = p.Lq;
     if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
     const bool live = r < qlen;
-    const float* qrow = (const float*)p.Q + ((int64_t)qi * p.Lq + (live ? r : 0)) * 128;
+    const int64_t qoff = ((int64_t)qi * p.Lq + (live ? r : 0)) * 128;
+    const float* qrow = (const float*)p.Q + qoff;
+    const bool qf32 = p.q_dtype == MAXSIM_F32;  // a 16-bit query is widened element by element (start-up only)
     if constexpr (DT == MAXSIM_F32) {
       float qs = 1.0f;
       if (MODE == MODE_DENSE && live && p.mask_dtype != MAXSIM_MASK_NONE)
         qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + r);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        f32x4 v = *(const f32x4*)(qrow + 4 * hh + 32 * (i >> 2) + 8 * (i & 3));
+        const int e0 = 4 * hh + 32 * (i >> 2) + 8 * (i & 3);
+        f32x4 v;
+        if (qf32) {
+          v = *(const f32x4*)(qrow + e0);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, qoff + e0 + t);
+        }
         if (MODE == MODE_DENSE) v *= qs;  // Q * q_mask[..., None], BaseModel.py:42
         qv[i] = live ? v : (f32x4)(0.0f);
       }
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
-        f32x4 v0 = *(const f32x4*)(qrow + 8 * hh + 16 * i);
-        f32x4 v1 = *(const f32x4*)(qrow + 8 * hh + 16 * i + 4);
-        float q[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        float q[8];
+        if (qf32) {
+          const f32x4 v0 = *(const f32x4*)(qrow + 8 * hh + 16 * i);
+          const f32x4 v1 = *(const f32x4*)(qrow + 8 * hh + 16 * i + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { q[j] = v0[j]; q[4 + j] = v1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) q[j] = load_q(p.Q, p.q_dtype, qoff + 8 * hh + 16 * i + j);
+        }
         uint16_t pc[NP][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -261,35 +361,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     prev_issued = filled > 0;
   }
 
-  float rmax = NEG_INF;
-  float myscore = 0.0f;
-  int jdoc = 0;
+  Reducer red;
+  red.init();
   int buf = 0;
-
-  // A finished doc: exchange the lane halves (v_permlane32_swap), 0-floor, then sum the 32 query-token lanes with
-  // DPP adds -- a pairwise tree ((q0+q1)+(q2+q3))+... in VALU registers, no LDS round trips (a ds_bpermute
-  // butterfly costs ~6 dependent LDS latencies per doc, which dominates when docs are a few tokens long).
-  auto finalize = [&]() __attribute__((always_inline)) {  // C's current doc is complete
-    float sc;
-    if (C.kind == 0) {
-      const uint32_t xb = __float_as_uint(rmax);
-      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
-      float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      if (C.floor0) v = fmaxf(v, 0.0f);
-      v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
-      v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
-      v += dpp_f32<0x141>(v);  // row_half_mirror: 8-lane sums
-      v += dpp_f32<0x140>(v);  // row_mirror: 16-lane sums
-      // rows 0 and 1 hold the two halves of the 32 query tokens (rows 2, 3 mirror them)
-      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
-           __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
-    } else {
-      sc = C.kind == 1 ? 0.0f : NEG_INF;
-    }
-    if (lane == jdoc) myscore = sc;
-    ++jdoc;
-    rmax = NEG_INF;
-  };
 
   while (nconsumed < nissued) {
     // tiles c+1 .. c+NT-1 were issued after this one iff the previous step issued
@@ -362,52 +436,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
         sv[v] = (DT == MAXSIM_F16) ? fmaf(acc1[v], 1.0f / 2048.0f, acc0[v]) : (acc0[v] + acc1[v]);
     }
 
-    // ---- reduce: walk the document segments of this tile ---------------------------------------------------
-    int filled = 0;
-    while (filled < 32 && C.valid) {
-      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));  // 0: empty doc / padding slot
-      if (take == 32) {
-        float t0 = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
-        float t1 = fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7]));
-        float t2 = fmaxf(fmaxf(sv[8], sv[9]), fmaxf(sv[10], sv[11]));
-        float t3 = fmaxf(fmaxf(sv[12], sv[13]), fmaxf(sv[14], sv[15]));
-        rmax = fmaxf(rmax, fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
-      } else if (take > 0 && ((filled | take) & 7) == 0) {
-        // segment made of whole 8-row groups (e.g. the 8-token multi-view docs): group g = rows 8g..8g+7 is exactly
-        // accumulators 4g..4g+3 of both lane halves -> no per-row masking, wave-uniform group selection
-        float m = NEG_INF;
-        const int g0 = filled >> 3, g1 = (filled + take) >> 3;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const float mg = fmaxf(fmaxf(sv[4 * g], sv[4 * g + 1]), fmaxf(sv[4 * g + 2], sv[4 * g + 3]));
-          m = (g >= g0 && g < g1) ? fmaxf(m, mg) : m;
-        }
-        rmax = fmaxf(rmax, m);
-      } else if (take > 0) {  // rows [filled, filled + take) only; accumulator v of this lane is row (v&3) + 8 (v>>2) + 4 hh
-        float m = NEG_INF;
-        const uint32_t lo = (uint32_t)(filled - 4 * hh), n_in = (uint32_t)take;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) {
-          const uint32_t rel = (uint32_t)((v & 3) + 8 * (v >> 2)) - lo;
-          m = fmaxf(m, rel < n_in ? sv[v] : NEG_INF);
-        }
-        rmax = fmaxf(rmax, m);
-      }
-      filled += take;
-      C.pos += take;
-      if (C.pos >= C.len) {  // doc complete (empty docs / padding slots are scored on the spot)
-        finalize();
-        C.next_doc(dl);
-      }
-    }
+    red.reduce_tile(sv, C, dl, lane);
     ++nconsumed;
   }
-  while (C.valid) {  // trailing empty docs / padding slots
-    finalize();
-    C.next_doc(dl);
-  }
-
-  if (lane < jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = myscore;
+  red.drain(C, dl, lane);
+  if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
 }
 
 }  // namespace maxsim

@@ -1,0 +1,200 @@
+// maxsim_stream_bigh.h -- the streaming MFMA kernel for wide embeddings: h = 128 * KB (e.g. the reference's default
+// dim 768, proj_conf/dense.yaml:8), Lq <= 32, fp32 / fp16 / bf16 token matrix, rerank mode.
+//
+// Same token-stream structure as maxsim_stream.h (packed 32-row tiles, descriptor lanes, per-wave LDS-DMA ring, DPP
+// reduce), with the contraction split into KB blocks of 128 dims: a "sub-tile" is 32 rows x one 128-dim block (each
+// row contributes >= 256 contiguous bytes = whole cache lines), the accumulators live across the KB sub-tiles of a
+// tile, and the per-document reduction runs after the last block.  The query does not fit in registers at this
+// width, so the workgroup stages it ONCE in LDS in MFMA B-operand order -- per 128-dim block the same swizzled
+// [32 rows][128 dims] image as a doc sub-tile, so A and B operand reads use the same lane offsets -- as NPQ
+// pieces: 1 when the query arrives in the index's own 16-bit type (exact), else hi + lo (fp16: lo pre-scaled by
+// 2^11, exact to 2^-22; bf16: 16 significant bits, |error| ~1e-5 per token, inside the 1e-3 tolerance stated for
+// 16-bit inputs); fp32 index: the fp32 query itself (exact f32 MFMA chain).
+#pragma once
+#include "maxsim_stream.h"
+
+namespace maxsim {
+
+template <int DT, int NPQ, int WAVES, int NT>
+__global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
+  static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KARGS_TO_PARAMS;
+  constexpr int MODE = MODE_RERANK;
+  using T = StreamTraits<DT>;
+  constexpr int BLKB = T::ROWB;  // bytes of one 128-dim block of a row
+  constexpr int SUB = T::TILE;   // bytes of a sub-tile (32 rows x one block) == one query piece block
+  constexpr int NDMA = T::NDMA, RPD = T::RPD, LPR = T::LPR, NRD = T::NRD;
+  constexpr int ESZ = BLKB / 128;
+  const int KB = p.h >> 7;
+  const uint32_t rowbytes = (uint32_t)p.h * ESZ;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int qi = blockIdx.x / p.nchunk;
+  const int chunk = blockIdx.x - qi * p.nchunk;
+  const int dpwv = p.dpw / WAVES;
+  const int c_begin = chunk * p.dpw + wave * dpwv;
+  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  const DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, lane);
+  char* const qlds = lds;                                   // [NPQ][KB][32 rows][BLKB]
+  char* const wlds = lds + NPQ * KB * SUB + wave * (NT * SUB);
+  const int r = lane & 31, hh = lane >> 5;
+
+  // ---- stage the query tile in LDS (all waves), B-operand order, swizzled like a doc sub-tile --------------------
+  {
+    int qlen = p.Lq;
+    if (p.q_len) qlen = min(qlen, p.q_len[qi]);
+    constexpr int CPB = BLKB / 16;       // 16-byte chunks per row block
+    constexpr int EPC = 16 / ESZ;        // elements per chunk
+    const int nchunks = KB * 32 * CPB;
+    for (int idx = threadIdx.x; idx < nchunks; idx += WAVES * 64) {
+      const int c = idx % CPB;
+      const int n = (idx / CPB) & 31;
+      const int kb = idx / (CPB * 32);
+      const bool live = n < qlen;
+      const int64_t src = ((int64_t)qi * p.Lq + (live ? n : 0)) * p.h + kb * 128 + c * EPC;
+      float q[EPC];
+#pragma unroll
+      for (int j = 0; j < EPC; ++j) q[j] = live ? load_q(p.Q, p.q_dtype, src + j) : 0.0f;
+      char* dst = qlds + kb * SUB + n * BLKB + 16 * (c ^ (n & 15));
+      if constexpr (DT == MAXSIM_F32) {
+        *(f32x4*)dst = f32x4{q[0], q[1], q[2], q[3]};
+      } else {
+        uint16_t pc[2][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if constexpr (DT == MAXSIM_F16) {
+            _Float16 hi = (_Float16)q[j];
+            _Float16 lo = (_Float16)((q[j] - (float)hi) * 2048.0f);
+            __builtin_memcpy(&pc[0][j], &hi, 2);
+            __builtin_memcpy(&pc[1][j], &lo, 2);
+          } else {
+            pc[0][j] = f32_to_bf16_rn(q[j]);
+            pc[1][j] = f32_to_bf16_rn(q[j] - bf16_to_f32(pc[0][j]));
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < NPQ; ++k) {
+          u32x4 w;
+#pragma unroll
+          for (int x = 0; x < 4; ++x) w[x] = (uint32_t)pc[k][2 * x] | ((uint32_t)pc[k][2 * x + 1] << 16);
+          *(u32x4*)(dst + k * KB * SUB) = w;
+        }
+      }
+    }
+  }
+  __syncthreads();  // the only workgroup barrier: the query image is read-only from here on
+
+  const int dslot0 = lane / LPR;
+  const int dchunk = lane % LPR;
+  const int rsw = r & 15;
+  const int rdbase = r * BLKB;
+  const char* const tok = (const char*)p.index;
+
+  Cursor F, C;
+  F.init(dl, ndoc);
+  C = F;
+
+  // fetch side: the tile being fetched block by block
+  uint32_t f_myrow = 0, f_rowfirst = 0;
+  bool f_single = false, f_valid = false;
+  int fkb = 0;
+
+  auto fetch_next = [&](int buf) __attribute__((always_inline)) -> bool {
+    if (fkb == 0) f_valid = fill_tile(F, dl, r, f_myrow, f_single, f_rowfirst) > 0;
+    if (!f_valid) return false;
+    char* l = wlds + buf * SUB;
+    int ds0 = dslot0, dch = dchunk;
+    asm volatile("" : "+v"(ds0), "+v"(dch));
+    const uint32_t blk = (uint32_t)fkb * BLKB;
+    if (f_single) {
+      const char* base = tok + (uint64_t)f_rowfirst * rowbytes + blk;
+#pragma unroll
+      for (int i = 0; i < NDMA; ++i) {
+        const int slot = RPD * i + ds0;
+        const uint32_t off = (uint32_t)slot * rowbytes + 16u * (uint32_t)(dch ^ (slot & 15));
+        __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll 2
+      for (int i = 0; i < NDMA; ++i) {
+        const int slot = RPD * i + ds0;
+        const uint32_t row = (uint32_t)__shfl((int)f_myrow, slot);
+        const char* g = tok + (uint64_t)row * rowbytes + blk + 16u * (uint32_t)(dch ^ (slot & 15));
+        __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
+      }
+    }
+    fkb = (fkb + 1 == KB) ? 0 : fkb + 1;
+    return true;
+  };
+
+  int nissued = 0, nconsumed = 0;
+  bool prev_issued = false;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const bool ok = fetch_next(j);
+    nissued += ok ? 1 : 0;
+    prev_issued = ok;
+  }
+
+  Reducer red;
+  red.init();
+  int buf = 0, ckb = 0;
+  f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
+
+  while (nconsumed < nissued) {
+    if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
+    const char* tl = wlds + buf * SUB + rdbase;
+    u32x4 a[NRD];
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) a[i] = *(const u32x4*)(tl + 16 * ((2 * i + hh) ^ rsw));
+    wait_lgkmcnt0();
+    {
+      const bool ok = fetch_next(buf);
+      nissued += ok ? 1 : 0;
+      prev_issued = ok;
+    }
+    buf = (buf + 1 == NT) ? 0 : buf + 1;
+
+    const char* qb = qlds + ckb * SUB + rdbase;  // this block's query image, same lane offsets as the doc image
+#pragma unroll
+    for (int i = 0; i < NRD; ++i) {
+      const int qoff = 16 * ((2 * i + hh) ^ rsw);
+      if constexpr (DT == MAXSIM_F32) {
+        const f32x4 av = __builtin_bit_cast(f32x4, a[i]);
+        const f32x4 bv = *(const f32x4*)(qb + qoff);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc0, 0, 0, 0);
+      } else if constexpr (DT == MAXSIM_F16) {
+        const f16x8 av = __builtin_bit_cast(f16x8, a[i]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + qoff), acc0, 0, 0, 0);
+        if constexpr (NPQ == 2)
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + KB * SUB + qoff), acc1, 0, 0, 0);
+      } else {
+        const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + qoff), acc0, 0, 0, 0);
+        if constexpr (NPQ == 2)
+          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + KB * SUB + qoff), acc1, 0, 0, 0);
+      }
+    }
+    ckb = (ckb + 1 == KB) ? 0 : ckb + 1;
+    if (ckb == 0) {  // last block of the tile: similarities are complete
+      float sv[16];
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        if constexpr (NPQ == 2)
+          sv[v] = (DT == MAXSIM_F16) ? fmaf(acc1[v], 1.0f / 2048.0f, acc0[v]) : (acc0[v] + acc1[v]);
+        else
+          sv[v] = acc0[v];
+      }
+      red.reduce_tile(sv, C, dl, lane);
+      acc0 = (f32x16)(0.0f);
+      acc1 = (f32x16)(0.0f);
+    }
+    ++nconsumed;
+  }
+  red.drain(C, dl, lane);
+  if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
+}
+
+}  // namespace maxsim

@@ -84,7 +84,9 @@ class ColbertRanker:
         """Q [nq, Lq, h] (token-major), cand_pids [nq, ncand] int64 LOCAL pids (<0 = padding slot)
         -> scores [nq, ncand] fp32 on the device."""
         dev = self.device
-        Q = Q.to(device=dev, dtype=torch.float32).contiguous()
+        # a 16-bit query is passed through in its own dtype (no query bits are invented); anything else as fp32
+        qdt = Q.dtype if Q.dtype in (torch.float16, torch.bfloat16) else torch.float32
+        Q = Q.to(device=dev, dtype=qdt).contiguous()
         cand = cand_pids.to(device=dev, dtype=torch.int64).contiguous()
         nq, Lq, h = Q.shape
         assert h == self.dim, (h, self.dim)
@@ -95,7 +97,7 @@ class ColbertRanker:
         with torch.cuda.device(dev):
             rc = _lib.lib.maxsim_rerank(_ptr(self.tensor), _DT[self.tensor.dtype], self.num_embeddings,
                                         _ptr(self.d_offsets), _ptr(self.d_doclens), _ptr(self.d_pad_len),
-                                        self.n_docs, _ptr(Q), _ptr(ql), _ptr(cand), nq, ncand, Lq, h,
+                                        self.n_docs, _ptr(Q), _DT[qdt], _ptr(ql), _ptr(cand), nq, ncand, Lq, h,
                                         _ptr(scores), _stream(dev))
         if rc == _lib.EEMPTY:
             raise AssertionError("len(pids) > 0")  # colbert_ranker.py:76

@@ -83,16 +83,20 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
  *   tok_offsets [n_docs] int64  first token row of each doc (doclens prefix sum, colbert_ranker.py:32)
  *   doclens     [n_docs] int32
  *   pad_len     [n_docs] int32 or NULL
- *   Q           [nq, Lq, h] float32 (token-major; the Python shim undoes the reference's [1,h,Lq] permute)
+ *   Q           [nq, Lq, h] element type q_dtype (F32, or F16/BF16 when the encoder already emits 16-bit
+ *               queries); token-major (the Python shim undoes the reference's [1,h,Lq] permute)
  *   q_len       [nq] int32 or NULL (= Lq for every query); tokens m >= q_len[q] are dropped
  *               (what keep_nonzero does before search(), training_utils.py:48-53)
  *   cand_pids   [nq, ncand] int64; an entry < 0 or >= n_docs is a padding slot: its score is -inf
  *   scores      [nq, ncand] float32
  * A doc with doclens == 0 scores 0.  ncand == 0 -> MAXSIM_EEMPTY (colbert_ranker.py:76).
- * Fast paths: h == 128, Lq <= 32, index F32 (f32-input MFMA) or F16/BF16 (16-bit MFMA, Q split hi+lo).
+ * Fast paths (MFMA + LDS-DMA streaming): Lq <= 32 and h == 128 (query tile in registers; index F32: f32-input
+ * MFMA, exact; F16/BF16: 16-bit MFMA with the fp32 query split into 2/3 pieces, no query bits dropped) or
+ * h a multiple of 128 up to 1024 (query tile staged in LDS; e.g. the reference's default dim 768).
+ * n_tokens must be < 2^32 for the fast paths.  Everything else runs the generic kernel.
  */
 int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,
-                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const float* Q,
+                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const void* Q, int q_dtype,
                   const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
                   float* scores, void* stream);
 

@@ -47,9 +47,10 @@ def test_validation_without_launch(lib):
     assert L.maxsim_score_dense(None, None, None, None, 2, 2, 1, 0, 1, 0, 0, None, None) == lib.EEMPTY
     assert L.maxsim_score_dense(None, None, None, None, 2, 2, 1, 1, 1, 0, 0, None, None) == lib.EINVAL  # null out
     # rerank: empty candidate list = assert len(pids) > 0 (colbert_ranker.py:76)
-    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, None, None, 1, 0, 32, 128, None, None) == lib.EEMPTY
-    assert L.maxsim_rerank(None, 7, 0, None, None, None, 0, None, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
-    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
+    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, 0, None, None, 1, 0, 32, 128, None, None) == lib.EEMPTY
+    assert L.maxsim_rerank(None, 7, 0, None, None, None, 0, None, 0, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
+    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, 5, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
+    assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, 0, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
     # topk
     assert L.maxsim_topk(None, None, 1, 0, 1, None, None, None) == lib.EEMPTY
     assert L.maxsim_topk(None, None, 1, 20000, 1, None, None, None) == lib.ERANGE
