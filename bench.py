@@ -189,7 +189,7 @@ def main():
     if world == 1 and ndocs == wl["ndocs"] and not args.lq and os.path.exists(pmc):
         try:
             for k, v in json.load(open(pmc)).items():
-                if "maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
+                if "k_maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
                     traffic = int(v["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] + v.get("hbm_write_bytes_per_launch(WRITE_SIZE*1024)", 0))
         except (OSError, ValueError):
             traffic = None

@@ -110,32 +110,79 @@ __device__ __forceinline__ float dpp_f32(float v) {  // v as seen through the DP
   return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
 }
 
-// Lays the next 32 stream rows onto the tile's row slots.  `myrow` = token-matrix row of slot (lane & 31).
-// Returns the number of real rows (0: stream exhausted).  Slots past the stream end repeat the last real row
-// (a duplicate cannot change a max).  `single`: the tile is 32 consecutive rows of one doc starting at row_first.
-__device__ __forceinline__ int fill_tile(Cursor& F, const DocLanes& dl, int r, uint32_t& myrow, bool& single,
-                                         uint32_t& row_first) {
-  int filled = 0;
-  uint32_t last = 0;
-  single = false;
-  row_first = 0;
-  myrow = 0;
+// Where the 32 row slots of a tile come from.
+struct TileMap {
+  uint32_t myrow;         // token-matrix row of slot (lane & 31)
+  uint32_t base0, base1;  // first / second document segment: slot s -> row base + s
+  int split;              // first slot of the second segment
+  int kind;               // 0: stream exhausted; 1: 32 consecutive rows of one doc; 2: two segments; 3: anything else
+};
+
+// Lays the next 32 stream rows onto the tile's row slots.  Slots past the stream end repeat the last real row (a
+// duplicate cannot change a max).
+__device__ __forceinline__ TileMap fill_tile(Cursor& F, const DocLanes& dl, int r) {
+  int filled = 0, nseg = 0, split = 32;
+  uint32_t last = 0, myrow = 0, base0 = 0, base1 = 0;
   while (filled < 32 && F.valid) {
     const int take = uni(min(32 - filled, max(F.len - F.pos, 0)));  // 0: empty doc / padding slot, just skipped
     const uint32_t base = F.row0 + (uint32_t)F.pos - (uint32_t)filled;  // slot r -> row base + r
-    if (filled == 0 && take > 0) {
-      row_first = base;
-      single = (take == 32);
-    }
+    base0 = (take > 0 && nseg == 0) ? base : base0;
+    base1 = (take > 0 && nseg == 1) ? base : base1;
+    split = (take > 0 && nseg == 1) ? filled : split;
+    nseg += take > 0 ? 1 : 0;
     const bool in = (r >= filled) & (r < filled + take);
     myrow = in ? base + (uint32_t)r : myrow;
-    if (take > 0) last = base + (uint32_t)(filled + take - 1);
+    last = take > 0 ? base + (uint32_t)(filled + take - 1) : last;
     filled += take;
     F.pos += take;
     if (F.pos >= F.len) F.next_doc(dl);
   }
-  if (filled > 0 && filled < 32) myrow = (r >= filled) ? last : myrow;
-  return filled;
+  TileMap t;
+  t.myrow = (filled > 0 && r >= filled) ? last : myrow;
+  t.base0 = base0;
+  t.base1 = base1;
+  t.split = split;
+  t.kind = filled == 0 ? 0 : ((filled == 32 && nseg == 1) ? 1 : ((filled == 32 && nseg == 2) ? 2 : 3));
+  return t;
+}
+
+// Issues the NDMA LDS-DMA instructions of one tile (or of one 128-dim block of it): instruction i moves the RPD row
+// slots RPD*i + lane/LPR, 1 KiB in all, to l + 1024 i.  `rowbytes` = bytes per token row, `blk` = byte offset of the
+// block inside the row.  Chunk position p of slot m receives source chunk p ^ (m & 15).
+template <int NDMA, int RPD, int LPR>
+__device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, uint32_t blk, char* l,
+                                           const TileMap& t, int lane) {
+  // (the lane constants are made opaque so that hipcc recomputes the 2-3 VALU ops per instruction instead of keeping
+  //  NDMA loop-invariant offsets alive in VGPRs across the whole tile loop)
+  int ds0 = lane / LPR, dch = lane % LPR;
+  asm volatile("" : "+v"(ds0), "+v"(dch));
+  if (t.kind == 1) {  // one contiguous burst: uniform base in SGPRs + per-lane 32-bit offset
+    const char* base = tok + (uint64_t)t.base0 * rowbytes + blk;
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int slot = RPD * i + ds0;
+      const uint32_t off = (uint32_t)slot * rowbytes + 16u * (uint32_t)(dch ^ (slot & 15));
+      __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
+    }
+  } else if (t.kind == 2) {  // the end of one doc and the start of the next: two uniform bases, selected per lane
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int slot = RPD * i + ds0;
+      const uint32_t row = (slot < t.split ? t.base0 : t.base1) + (uint32_t)slot;
+      const char* g = tok + (uint64_t)row * rowbytes + blk + 16u * (uint32_t)(dch ^ (slot & 15));
+      __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
+    }
+  } else {  // many short docs (or the stream's padded last tile): each slot's row comes from the lane that owns it
+    uint32_t rows[NDMA];
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) rows[i] = (uint32_t)__shfl((int)t.myrow, RPD * i + ds0);
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const int slot = RPD * i + ds0;
+      const char* g = tok + (uint64_t)rows[i] * rowbytes + blk + 16u * (uint32_t)(dch ^ (slot & 15));
+      __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
+    }
+  }
 }
 
 // Per-wave reduction state: running max of the current doc (per lane: one query token, one lane half) and the
@@ -310,8 +357,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   }
 
   // ---- per-lane constants ------------------------------------------------------------------------------------
-  const int dslot0 = lane / LPR;  // DMA instruction i covers row slots RPD * i + dslot0
-  const int dchunk = lane % LPR;  // 16-byte chunk position inside the row
   const int rsw = r & 15;
   const int rdbase = r * ROWB;
   const char* const tok = (const char*)p.index;
@@ -320,30 +365,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   F.init(dl, ndoc);
   C = F;
 
-  auto issue_tile = [&](int buf, uint32_t myrow, bool single, uint32_t row_first) __attribute__((always_inline)) {
+  auto issue_tile = [&](int buf, const TileMap& t) __attribute__((always_inline)) {
     if (ABLATE == 2) return;
-    char* l = wlds + buf * TILE;
-    // (the lane constants are made opaque here so that hipcc recomputes the 2-3 VALU ops per instruction instead
-    //  of keeping NDMA loop-invariant offsets alive in VGPRs across the whole tile loop)
-    int ds0 = dslot0, dch = dchunk;
-    asm volatile("" : "+v"(ds0), "+v"(dch));
-    if (single) {  // one contiguous burst: uniform base in SGPRs + per-lane 32-bit offset
-      const char* base = tok + (uint64_t)row_first * ROWB;
-#pragma unroll
-      for (int i = 0; i < NDMA; ++i) {
-        const int slot = RPD * i + ds0;
-        const uint32_t off = (uint32_t)slot * ROWB + 16u * (uint32_t)(dch ^ (slot & 15));
-        __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
-      }
-    } else {  // rows of several docs: each slot's row comes from the lane that owns the slot
-#pragma unroll 2
-      for (int i = 0; i < NDMA; ++i) {
-        const int slot = RPD * i + ds0;
-        const uint32_t row = (uint32_t)__shfl((int)myrow, slot);
-        const char* g = tok + (uint64_t)row * ROWB + 16u * (uint32_t)(dch ^ (slot & 15));
-        __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
-      }
-    }
+    issue_rows<NDMA, RPD, LPR>(tok, (uint32_t)ROWB, 0u, wlds + buf * TILE, t, lane);
   };
 
   // ---- prologue: up to NT tiles in flight -----------------------------------------------------------------------
@@ -351,14 +375,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   bool prev_issued = false;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    uint32_t myrow, row_first;
-    bool single;
-    const int filled = fill_tile(F, dl, r, myrow, single, row_first);
-    if (filled > 0) {
-      issue_tile(j, myrow, single, row_first);
+    const TileMap t = fill_tile(F, dl, r);
+    if (t.kind != 0) {
+      issue_tile(j, t);
       ++nissued;
     }
-    prev_issued = filled > 0;
+    prev_issued = t.kind != 0;
   }
 
   Reducer red;
@@ -374,14 +396,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     for (int i = 0; i < NRD; ++i) a[i] = *(const u32x4*)(tl + 16 * ((2 * i + hh) ^ rsw));
     wait_lgkmcnt0();  // operands are in registers: the buffer may be overwritten
     {
-      uint32_t myrow, row_first;
-      bool single;
-      const int filled = fill_tile(F, dl, r, myrow, single, row_first);
-      if (filled > 0) {
-        issue_tile(buf, myrow, single, row_first);
+      const TileMap t = fill_tile(F, dl, r);
+      if (t.kind != 0) {
+        issue_tile(buf, t);
         ++nissued;
       }
-      prev_issued = filled > 0;
+      prev_issued = t.kind != 0;
     }
     buf = (buf + 1 == NT) ? 0 : buf + 1;
 
@@ -389,10 +409,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     if constexpr (MODE == MODE_DENSE) {  // D * d_mask[..., None], BaseModel.py:41
       if (p.mask_dtype != MAXSIM_MASK_NONE) {
         Cursor Cp = C;
-        uint32_t crow, rf;
-        bool sg;
-        fill_tile(Cp, dl, r, crow, sg, rf);
-        mv = load_mask(p.d_mask, p.mask_dtype, (int64_t)crow);
+        const TileMap ct = fill_tile(Cp, dl, r);
+        mv = load_mask(p.d_mask, p.mask_dtype, (int64_t)ct.myrow);
       }
     }
 

@@ -85,8 +85,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   }
   __syncthreads();  // the only workgroup barrier: the query image is read-only from here on
 
-  const int dslot0 = lane / LPR;
-  const int dchunk = lane % LPR;
   const int rsw = r & 15;
   const int rdbase = r * BLKB;
   const char* const tok = (const char*)p.index;
@@ -96,34 +94,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   C = F;
 
   // fetch side: the tile being fetched block by block
-  uint32_t f_myrow = 0, f_rowfirst = 0;
-  bool f_single = false, f_valid = false;
+  TileMap ft;
+  ft.myrow = 0; ft.base0 = 0; ft.base1 = 0; ft.split = 32; ft.kind = 0;
   int fkb = 0;
-
   auto fetch_next = [&](int buf) __attribute__((always_inline)) -> bool {
-    if (fkb == 0) f_valid = fill_tile(F, dl, r, f_myrow, f_single, f_rowfirst) > 0;
-    if (!f_valid) return false;
-    char* l = wlds + buf * SUB;
-    int ds0 = dslot0, dch = dchunk;
-    asm volatile("" : "+v"(ds0), "+v"(dch));
-    const uint32_t blk = (uint32_t)fkb * BLKB;
-    if (f_single) {
-      const char* base = tok + (uint64_t)f_rowfirst * rowbytes + blk;
-#pragma unroll
-      for (int i = 0; i < NDMA; ++i) {
-        const int slot = RPD * i + ds0;
-        const uint32_t off = (uint32_t)slot * rowbytes + 16u * (uint32_t)(dch ^ (slot & 15));
-        __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll 2
-      for (int i = 0; i < NDMA; ++i) {
-        const int slot = RPD * i + ds0;
-        const uint32_t row = (uint32_t)__shfl((int)f_myrow, slot);
-        const char* g = tok + (uint64_t)row * rowbytes + blk + 16u * (uint32_t)(dch ^ (slot & 15));
-        __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
-      }
-    }
+    if (fkb == 0) ft = fill_tile(F, dl, r);
+    if (ft.kind == 0) return false;
+    issue_rows<NDMA, RPD, LPR>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
     fkb = (fkb + 1 == KB) ? 0 : fkb + 1;
     return true;
   };

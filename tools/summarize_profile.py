@@ -46,7 +46,7 @@ def main():
         if not cc:
             continue
         for r in csv.DictReader(open(cc)):
-            if "maxsim" not in r["Kernel_Name"]:
+            if "k_maxsim" not in r["Kernel_Name"]:
                 continue
             k = short(r["Kernel_Name"]).split("(")[0]
             e = out.setdefault(k, {}).setdefault(r["Counter_Name"], [])
