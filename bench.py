@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="with --gpus 1: still initialise RCCL (world 1) and run the all_gather + merge leg")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -102,8 +104,11 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import colbert_amd
     from colbert_amd.sharded import ShardedRanker
@@ -151,7 +156,7 @@ def main():
         scores = ranker.score_candidates(Q, cand_local)
         ev[i][1].record()
         top_p, top_s = ranker.topk(scores, cand_global, TOPK if per >= TOPK else per)
-        if world > 1:
+        if use_dist:
             from colbert_amd.sharded import all_gather_topk, merge_gathered
             gs, gp = all_gather_topk(top_s, top_p, world)
             top_p, top_s = merge_gathered(gs, gp, TOPK, ranker.topk)
@@ -159,18 +164,18 @@ def main():
 
     for i in range(args.warmup):
         step(i)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.warmup, total):
         out = step(i)
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
@@ -214,7 +219,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

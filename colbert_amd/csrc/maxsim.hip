@@ -6,6 +6,7 @@
 // Kernels: maxsim_stream.h (MFMA + LDS-DMA streaming kernel, the hot path), maxsim_generic.h (any-shape
 // correctness kernel), maxsim_topk.h (per-query top-k).  This file holds the launch heuristics and the C ABI
 // declared in include/maxsim.h.  gfx950 only: no CUDA, no hipify, no dual paths.
+#include "maxsim_candidates.h"
 #include "maxsim_common.h"
 #include "maxsim_generic.h"
 #include "maxsim_stream.h"
@@ -223,6 +224,24 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
   int threads = P / 2 < 64 ? 64 : (P / 2 > 1024 ? 1024 : P / 2);
   hipLaunchKernelGGL(k_topk, dim3((unsigned)nq), dim3(threads), ldsb, (hipStream_t)stream, scores, pids, ncand, k,
                      P, out_scores, out_pids);
+  return check_launch();
+}
+
+int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,
+                                 int64_t n_tokens, int64_t* out_pids, int32_t* out_count, void* stream) {
+  if (nq < 0 || n < 0 || n_docs < 0 || n_tokens < 0) return MAXSIM_EINVAL;
+  if (n == 0) return MAXSIM_EEMPTY;
+  if (n > 16384 || n_docs > 0xfffffffeLL) return MAXSIM_ERANGE;
+  if (nq == 0) return MAXSIM_OK;
+  if (!emb_ids || !tok_offsets || !out_pids || !out_count) return MAXSIM_EINVAL;
+  int P = 2;
+  while (P < n) P <<= 1;
+  const int threads = P / 2 < 64 ? 64 : (P / 2 > 1024 ? 1024 : P / 2);
+  const int ldsb = P * 4 + threads * 4;
+  int rc = allow_lds(k_unique_pids, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_unique_pids, dim3((unsigned)nq), dim3(threads), ldsb, (hipStream_t)stream, emb_ids, n, P,
+                     tok_offsets, n_docs, n_tokens, out_pids, out_count);
   return check_launch();
 }
 

@@ -125,6 +125,27 @@ class ColbertRanker:
         return self.topk(scores, cand_pids, k)
 
     # ------------------------------------------------------------------------------------------
+    def embedding_ids_to_pids(self, embedding_ids, trim=True):
+        """GPU form of ``ColbertIndex.embedding_ids_to_pids`` (colbert_ranker.py:212-229): token rows returned by the
+        ANN search, ``[nq, Lq * faiss_depth]`` int64 (as reshaped at colbert_ranker.py:178), -> per-query DISTINCT pids,
+        ascending, padded with -1: a ``cand_pids`` matrix for ``rerank_batch`` -- no ``.tolist()`` / ``set()`` /
+        ``Pool(16)`` hop through the host.  Returns ``(cand [nq, width], counts [nq])``; ``trim`` cuts the width to the
+        largest count (one host sync)."""
+        dev = self.device
+        e = embedding_ids.to(device=dev, dtype=torch.int64).contiguous()
+        assert e.dim() == 2
+        nq, n = e.shape
+        out = torch.empty(nq, n, dtype=torch.int64, device=dev)
+        cnt = torch.empty(nq, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib.maxsim_embedding_ids_to_pids(_ptr(e), nq, n, _ptr(self.d_offsets), self.n_docs,
+                                                       self.num_embeddings, _ptr(out), _ptr(cnt), _stream(dev))
+        _lib.check(rc, "maxsim_embedding_ids_to_pids")
+        if trim and nq > 0:
+            out = out[:, :max(int(cnt.max().item()), 1)].contiguous()
+        return out, cnt
+
+    # ------------------------------------------------------------------------------------------
     def rank_forward(self, Q, pids, views=None, depth=10, output_D_embedding=False):
         """colbert_ranker.py:75-137.  Q is [1, h, Lq] (dim-major, as faiss_indexers.py:232-233 hands it over)."""
         assert len(pids) > 0                                                  # :76

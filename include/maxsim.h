@@ -12,6 +12,7 @@
  *                           colbert/training/dense_server_client.py:44-48)
  *   maxsim_topk         <- sort(descending)+[:depth]                  colbert/ranking/colbert_ranker.py:128-130
  *                          (also the per-query merge after the doc-sharded RCCL all-gather)
+ *   maxsim_embedding_ids_to_pids <- ColbertIndex.embedding_ids_to_pids colbert/ranking/colbert_ranker.py:212-229
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensors); the library allocates
@@ -109,6 +110,18 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
  */
 int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
                 int64_t* out_pids, void* stream);
+
+/*
+ * Candidate-side glue: ANN result (embedding ids) -> per-query distinct pid lists, the GPU form of
+ * ColbertIndex.embedding_ids_to_pids (colbert_ranker.py:212-229: emb2pid lookup + per-query set()).  The pid of a
+ * token row is found by binary search in tok_offsets (no separate emb2pid table, colbert_ranker.py:163-174).
+ *   emb_ids   [nq, n] int64 token rows (FAISS ids); entries < 0 or >= n_tokens are dropped
+ *   out_pids  [nq, n] int64: the query's distinct pids ascending, then -1 padding (directly usable as cand_pids)
+ *   out_count [nq] int32: number of distinct pids
+ * 1 <= n <= 16384 (= 32 query tokens x faiss_depth 512, the reference's BSIZE); n_docs < 2^32 - 1.
+ */
+int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,
+                                 int64_t n_tokens, int64_t* out_pids, int32_t* out_count, void* stream);
 
 #ifdef __cplusplus
 }

@@ -159,6 +159,35 @@ def test_ragged_rerank_golden(ca, golden, dtype):
     assert len(tp2) == 7 and ts2 == sorted(ts2, reverse=True)
 
 
+def test_ranker_from_index_files_and_output_D(ca, golden, tmp_path):
+    """The reference's on-disk format ({i}.pt + doclens.{i}.json) loads into the HBM-resident ranker
+    (colbert_ranker.py:16-29,61-73), and output_D_embedding=True returns (pids, D, mask) (:131-136)."""
+    from colbert_amd import index_io
+    from oracle.maxsim_oracle import RefRanker
+    g = golden("ragged_rerank_64")
+    parts = [g["part0"], g["part1"]]
+    pdl = [g["doclens0"].tolist(), g["doclens1"].tolist()]
+    d = str(tmp_path / "idx")
+    index_io.save_index(d, parts, pdl)
+    r = ca.ColbertRanker(index_path=d, model=ca.MaxSimModel(), dim=128)        # the reference's ctor keywords
+    assert r.tensor.dtype == torch.float16 and r.num_embeddings == sum(map(sum, pdl))
+    tp, ts = r.rank_forward(g["Q"], g["pids"].tolist(), depth=10)
+    assert tp == g["top10_pids"].tolist()
+    np.testing.assert_allclose(ts, g["top10_scores"].numpy(), rtol=0, atol=ATOL32)
+    # output_D_embedding: the reference can only cat() candidates of ONE length bucket; pick such a set
+    ref = RefRanker(parts, pdl, dim=128)
+    pad = ref.bucket_strides(list(range(64)))
+    S = int(pad.max())
+    same = [i for i in range(64) if int(pad[i]) == S][:6]
+    ep, eD, em = ref.rank_forward(g["Q"], same, depth=4, output_D_embedding=True)
+    gp, gD, gm = r.rank_forward(g["Q"], same, depth=4, output_D_embedding=True)
+    assert gp == ep and tuple(gD.shape) == tuple(eD.shape) and torch.equal(gm.cpu(), em)
+    # slots under the mask are the doc's tokens; slots past the doc end are never used unmasked
+    torch.testing.assert_close(gD.cpu() * em.unsqueeze(-1), eD * em.unsqueeze(-1), rtol=0, atol=0)
+    with pytest.raises(RuntimeError):
+        r.rank_forward(g["Q"], list(range(64)), depth=64, output_D_embedding=True)   # spans several buckets
+
+
 def test_rank_forward_asserts(ca, golden):
     g = golden("ragged_rerank_64")
     r = _golden_ranker(ca, g, torch.float16)
@@ -316,3 +345,57 @@ def test_c2_full_batch_properties(ca):
     own = D3[cand[:, 0], :32].contiguous()
     s_own = r.score_candidates(own, cand[:, :1])
     torch.testing.assert_close(s_own.cpu(), torch.full((nq, 1), 32.0), rtol=0, atol=1e-3)
+
+
+# ------------------------------------------------------------------------------------------------------
+# candidate-side glue: colbert_ranker.py:163-174 (emb2pid) + :212-229 (per-query set())
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 37, 1000, 4096, 16384])
+def test_embedding_ids_to_pids(ca, n):
+    gen = torch.Generator().manual_seed(n)
+    doclens = torch.randint(0, 40, (500,), generator=gen).tolist()       # includes empty docs
+    doclens[0] = 3
+    ntok = sum(doclens)
+    r = ca.ColbertRanker(parts=[torch.zeros(ntok, 8)], parts_doclens=[doclens], dim=8)
+    # the reference's table, build_emb2pid (colbert_ranker.py:163-174)
+    emb2pid = torch.zeros(ntok, dtype=torch.int64)
+    o = 0
+    for pid, dl in enumerate(doclens):
+        emb2pid[o:o + dl] = pid
+        o += dl
+    nq = 3
+    e = torch.randint(0, ntok, (nq, n), generator=gen)
+    if n >= 37:
+        e[0, :30] = e[0, 0]                    # heavy duplication
+        e[1, 5] = -1                           # FAISS "no neighbour"
+        e[2, :] = torch.randint(0, 50, (n,), generator=gen)
+    cand, cnt = r.embedding_ids_to_pids(e, trim=False)
+    assert cand.shape == (nq, n)
+    for qi in range(nq):
+        ids = e[qi][e[qi] >= 0]
+        exp = sorted(set(emb2pid[ids].tolist()))                          # uniq(), colbert_ranker.py:234
+        c = int(cnt[qi])
+        assert cand[qi, :c].tolist() == exp
+        assert bool((cand[qi, c:] == -1).all())
+    cand_t, _ = r.embedding_ids_to_pids(e)
+    assert cand_t.shape[1] == max(int(cnt.max()), 1) and torch.equal(cand_t, cand[:, :cand_t.shape[1]])
+
+
+def test_retrieve_then_rerank_end_to_end(ca):
+    """ANN ids -> distinct pids -> fused rerank -> top-k equals the reference flow (search(): colbert_ranker.py:176-181
+    + rank_forward) on the oracle."""
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(5)
+    doclens = torch.randint(1, 60, (300,), generator=gen).tolist()
+    parts = [nrm(gen, sum(doclens), 128).half()]
+    ref = RefRanker(parts, [doclens], dim=128)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=[doclens], dim=128)
+    Q = nrm(gen, 4, 32, 128)
+    e = torch.randint(0, sum(doclens), (4, 32 * 16), generator=gen)
+    cand, cnt = r.embedding_ids_to_pids(e)
+    tp, ts = r.rerank_batch(Q, cand, depth=10)
+    for qi in range(4):
+        pids = cand[qi, :int(cnt[qi])].tolist()
+        ep, es = ref.rank_forward(Q[qi:qi + 1].permute(0, 2, 1), pids, depth=10)
+        np.testing.assert_allclose(ts[qi].cpu().numpy(), np.array(es), rtol=0, atol=ATOL32)
+        assert tp[qi].tolist() == ep
