@@ -93,6 +93,8 @@ def main():
     ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
+    ap.add_argument("--fp32-mode", default="exact", choices=["exact", "fast"],
+                    help="fp32 index only: exact f32 MFMA (default) or the split-fp16 fast mode")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still initialise RCCL (world 1) and run the all_gather + merge leg")
@@ -129,6 +131,7 @@ def main():
     idx = build_index(ntok, H, dev, 1234 + rank, dtype)
     ranker = colbert_amd.ColbertRanker.__new__(colbert_amd.ColbertRanker)
     ranker.maxsim_dtype = torch.float32
+    ranker.fp32_mode = args.fp32_mode
     ranker.device = dev
     ranker.model = None
     ranker.pid_offset = rank * ndocs
@@ -210,7 +213,7 @@ def main():
                                    f"{'~120 (8..180 ragged)' if wl['ragged'] else LD} tokens, dim {H}, "
                                    f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}",
                        "queries_per_step": nq, "candidates_per_query": NCAND, "docs_per_gpu": ndocs,
-                       "index_dtype": args.index_dtype, "parallelism": f"doc-shard x{world}"},
+                       "index_dtype": args.index_dtype, "fp32_mode": args.fp32_mode, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),

@@ -62,7 +62,7 @@ int launch_stream_v(Params& p, hipStream_t st) {
 // workgroups per CU.  MAXSIM_VARIANT is a diagnostic knob (DESIGN.md "Tuning knobs"): 1/2 = ablation builds.
 template <int MODE, int DT>
 int launch_stream(Params& p, hipStream_t st) {
-  constexpr int NT0 = (DT == MAXSIM_F32) ? 1 : 2;
+  constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
   switch (env_int("MAXSIM_VARIANT", 0)) {
     case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)
     case 2: return launch_stream_v<MODE, DT, 4, NT0, 2>(p, st);  // no DMA   (timing only, wrong results)
@@ -175,7 +175,7 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
                   const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
                   float* scores, void* stream) {
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
-  if (index_dtype < MAXSIM_F32 || index_dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
+  if (index_dtype < MAXSIM_F32 || index_dtype > MAXSIM_F32_FAST) return MAXSIM_EINVAL;
   if (q_dtype < MAXSIM_F32 || q_dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
   if (ncand == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
   if (nq == 0) return MAXSIM_OK;
@@ -199,14 +199,15 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
   p.mask_dtype = MAXSIM_MASK_NONE;
   if (h == 128 && Lq >= 1 && Lq <= 32 && n_tokens > 0 && n_tokens <= 0xffffffffLL) {
     if (index_dtype == MAXSIM_F32) return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
+    if (index_dtype == MAXSIM_F32_FAST) return launch_stream<MODE_RERANK, MAXSIM_F32_FAST>(p, st);
     if (index_dtype == MAXSIM_F16) return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
     return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
   }
   if (h > 128 && h <= 1024 && (h & 127) == 0 && Lq >= 1 && Lq <= 32 && n_tokens > 0 && n_tokens <= 0xffffffffLL) {
-    int rc = launch_bigh(p, index_dtype, st);
+    int rc = launch_bigh(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
     if (rc != MAXSIM_ERANGE) return rc;
   }
-  return launch_generic<MODE_RERANK>(p, index_dtype, st);
+  return launch_generic<MODE_RERANK>(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
 }
 
 int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,

@@ -29,6 +29,15 @@ template <>
 struct StreamTraits<MAXSIM_F32> {
   static constexpr int ROWB = 512, TILE = 16384, NDMA = 16, RPD = 2, LPR = 32, NRD = 16, NP = 1;
 };
+// fp32 storage, "fast" contraction: both operands are split on the fly into fp16 pieces (x = hi + 2^-11 lo) and the
+// products hi*hi, hi*lo, lo*hi run on the 16-bit matrix pipe (the 2^-22 lo*lo term is dropped): |error| ~ 2^-22
+// relative per product (~1e-6 on a score), 3x less matrix-pipe time than the exact f32 MFMA.  Needs |x| < 65504
+// (L2-normalised embeddings).  Opt-in: index_dtype MAXSIM_F32_FAST.
+constexpr int F32S = MAXSIM_F32_FAST;
+template <>
+struct StreamTraits<F32S> {
+  static constexpr int ROWB = 512, TILE = 16384, NDMA = 16, RPD = 2, LPR = 32, NRD = 16, NP = 2;
+};
 template <>
 struct StreamTraits<MAXSIM_F16> {
   static constexpr int ROWB = 256, TILE = 8192, NDMA = 8, RPD = 4, LPR = 16, NRD = 8, NP = 2;
@@ -271,7 +280,7 @@ struct Reducer {
 
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
-  static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is fp32 only");
+  static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   using T = StreamTraits<DT>;
@@ -290,6 +299,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   // ---- query tile -> registers in MFMA B layout --------------------------------------------------------------
   // fp32: lane (n, hh) holds Q[n][32 s + 8 u + 4 hh + t]   in qv[4 s + u][t]
   // 16b : lane (n, hh) holds Q[n][16 i + 8 hh + j], j=0..7 in qp[piece][i] (packed pairs)
+  constexpr bool F16Q = (DT == MAXSIM_F16 || DT == F32S);  // query split into fp16 hi + 2^-11 lo
   f32x4 qv[DT == MAXSIM_F32 ? 16 : 1];
   u32x4 qp[DT == MAXSIM_F32 ? 1 : NP][DT == MAXSIM_F32 ? 1 : 8];
   {
@@ -333,7 +343,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float x = live ? q[j] : 0.0f;
-          if constexpr (DT == MAXSIM_F16) {
+          if constexpr (F16Q) {
             _Float16 hi = (_Float16)x;
             _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
             __builtin_memcpy(&pc[0][j], &hi, 2);
@@ -393,7 +403,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     const char* tl = wlds + buf * TILE + rdbase;
     u32x4 a[NRD];
 #pragma unroll
-    for (int i = 0; i < NRD; ++i) a[i] = *(const u32x4*)(tl + 16 * ((2 * i + hh) ^ rsw));
+    for (int i = 0; i < NRD; ++i) {
+      // chunk of the row this lane needs for operand i: 16-bit MFMA k-step = 8 consecutive dims per lane half
+      const int c = (DT == F32S) ? (4 * (i >> 1) + 2 * hh + (i & 1)) : (2 * i + hh);
+      a[i] = *(const u32x4*)(tl + 16 * (c ^ rsw));
+    }
     wait_lgkmcnt0();  // operands are in registers: the buffer may be overwritten
     {
       const TileMap t = fill_tile(F, dl, r);
@@ -430,6 +444,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) sv[v] = acc[v];
+    } else if constexpr (DT == F32S) {
+      f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const f32x4 x0 = __builtin_bit_cast(f32x4, a[2 * i]), x1 = __builtin_bit_cast(f32x4, a[2 * i + 1]);
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(x0), "v"(x1));
+          continue;
+        }
+        f16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = j < 4 ? x0[j & 3] : x1[j & 3];
+          const _Float16 h = (_Float16)x;
+          hi[j] = h;
+          lo[j] = (_Float16)((x - (float)h) * 2048.0f);
+        }
+        const f16x8 qh = __builtin_bit_cast(f16x8, qp[0][i]), ql = __builtin_bit_cast(f16x8, qp[1][i]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, qh, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(hi, ql, acc1, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(lo, qh, acc1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sv[v] = fmaf(acc1[v], 1.0f / 2048.0f, acc0[v]);
     } else {
       f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
 #pragma unroll

@@ -34,10 +34,13 @@ class ColbertRanker:
     device                : the GPU holding the index
     index_dtype           : storage dtype in HBM (reference: fp16, colbert_ranker.py:62)
     pid_offset            : global pid of local doc 0 (doc-sharded multi-GPU)
+    fp32_mode             : for an fp32 index with dim 128: "exact" (default; f32-input MFMA, an exact fp32 fmaf chain)
+                            or "fast" (both operands split into fp16 pieces on the fly, 16-bit MFMA, |error| ~1e-6 on a
+                            score, needs |x| < 65504 -- fine for L2-normalised embeddings)
     """
 
     def __init__(self, index_path=None, model=None, dim=None, *, parts=None, parts_doclens=None, device="cuda",
-                 index_dtype=torch.float16, pid_offset=0):
+                 index_dtype=torch.float16, pid_offset=0, fp32_mode="exact"):
         if index_path is not None:
             _, parts_paths, _ = index_io.get_parts(index_path)                # :18
             parts_doclens = index_io.load_doclens(index_path, flatten=False)  # :22
@@ -49,6 +52,8 @@ class ColbertRanker:
         self.model = model
         self.device = torch.device(device)
         self.pid_offset = int(pid_offset)
+        assert fp32_mode in ("exact", "fast")
+        self.fp32_mode = fp32_mode
         doclens = [int(x) for y in parts_doclens for x in y]                  # flatten, utils.py:133
         self.num_embeddings = sum(doclens)
         dim = parts[0].size(-1) if dim is None else dim
@@ -95,7 +100,10 @@ class ColbertRanker:
         ql = None if q_len is None else q_len.to(device=dev, dtype=torch.int32).contiguous()
         scores = torch.empty(nq, ncand, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.lib.maxsim_rerank(_ptr(self.tensor), _DT[self.tensor.dtype], self.num_embeddings,
+            idt = _DT[self.tensor.dtype]
+            if idt == _lib.F32 and getattr(self, "fp32_mode", "exact") == "fast":
+                idt = _lib.F32_FAST
+            rc = _lib.lib.maxsim_rerank(_ptr(self.tensor), idt, self.num_embeddings,
                                         _ptr(self.d_offsets), _ptr(self.d_doclens), _ptr(self.d_pad_len),
                                         self.n_docs, _ptr(Q), _DT[qdt], _ptr(ql), _ptr(cand), nq, ncand, Lq, h,
                                         _ptr(scores), _stream(dev))

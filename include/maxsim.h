@@ -36,6 +36,9 @@ extern "C" {
 #define MAXSIM_F32 0
 #define MAXSIM_F16 1
 #define MAXSIM_BF16 2
+/* maxsim_rerank index_dtype only: fp32 storage, contraction on the 16-bit matrix pipe with BOTH operands split
+   into fp16 pieces on the fly (|error| ~1e-6 on a score; needs |x| < 65504, e.g. L2-normalised embeddings) */
+#define MAXSIM_F32_FAST 3
 
 /* element types of the mask tensors of maxsim_score_dense */
 #define MAXSIM_MASK_NONE 0 /* both mask pointers ignored: all ones */

@@ -399,3 +399,26 @@ def test_retrieve_then_rerank_end_to_end(ca):
         ep, es = ref.rank_forward(Q[qi:qi + 1].permute(0, 2, 1), pids, depth=10)
         np.testing.assert_allclose(ts[qi].cpu().numpy(), np.array(es), rtol=0, atol=ATOL32)
         assert tp[qi].tolist() == ep
+
+
+def test_fp32_fast_mode(ca, golden):
+    """fp32 index, opt-in "fast" contraction (both operands split into fp16 pieces, 16-bit MFMA): same scores to 1e-5."""
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(21)
+    parts, pdl = _random_index(gen, 300, 128, 1, 180, torch.float32)
+    ref = RefRanker(parts, pdl, dim=128, index_dtype=torch.float32)
+    exact = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=128, index_dtype=torch.float32)
+    fast = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=128, index_dtype=torch.float32, fp32_mode="fast")
+    Q = nrm(gen, 4, 32, 128)
+    cand = torch.stack([torch.randperm(300, generator=gen)[:120] for _ in range(4)])
+    se, sf = exact.score_candidates(Q, cand).cpu(), fast.score_candidates(Q, cand).cpu()
+    for qi in range(4):
+        exp = ref.all_scores(Q[qi:qi + 1].permute(0, 2, 1), cand[qi].tolist())
+        torch.testing.assert_close(sf[qi], exp, rtol=0, atol=1e-5)
+    assert float((se - sf).abs().max()) <= 1e-5
+    g = golden("ragged_rerank_64")
+    r = ca.ColbertRanker(parts=[g["part0"], g["part1"]], parts_doclens=[g["doclens0"].tolist(), g["doclens1"].tolist()],
+                         dim=128, index_dtype=torch.float32, fp32_mode="fast")
+    tp, ts = r.rank_forward(g["Q"], g["pids"].tolist(), depth=10)
+    assert tp == g["top10_pids"].tolist()
+    np.testing.assert_allclose(ts, g["top10_scores"].numpy(), rtol=0, atol=1e-5)
