@@ -15,7 +15,7 @@ MASK_NONE, MASK_I64, MASK_I32, MASK_F32, MASK_U8 = 0, 1, 2, 3, 4
 OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 
 SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk",
-           "maxsim_embedding_ids_to_pids")
+           "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd")
 
 
 class MaxSimError(RuntimeError):
@@ -44,6 +44,10 @@ def _load():
     lib.maxsim_rerank.argtypes = [vp, i32, i64, vp, vp, vp, i64, vp, i32, vp, vp, i32, i32, i32, i32, vp, vp]
     lib.maxsim_topk.restype = i32
     lib.maxsim_topk.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.maxsim_score_dense_fwd.restype = i32
+    lib.maxsim_score_dense_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.maxsim_score_dense_bwd.restype = i32
+    lib.maxsim_score_dense_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
     return lib

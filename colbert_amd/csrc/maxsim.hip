@@ -6,6 +6,7 @@
 // Kernels: maxsim_stream.h (MFMA + LDS-DMA streaming kernel, the hot path), maxsim_generic.h (any-shape
 // correctness kernel), maxsim_topk.h (per-query top-k).  This file holds the launch heuristics and the C ABI
 // declared in include/maxsim.h.  gfx950 only: no CUDA, no hipify, no dual paths.
+#include "maxsim_backward.h"
 #include "maxsim_candidates.h"
 #include "maxsim_common.h"
 #include "maxsim_generic.h"
@@ -71,16 +72,16 @@ int launch_stream(Params& p, hipStream_t st) {
   }
 }
 
-// Wide embeddings (h = 128 * KB): query image in LDS (NPQ x KB x sub-tile bytes), the rest of the 160 KiB goes to the
-// waves' rings: as many waves (<= 8) as fit with NT sub-tiles each.
-template <int DT, int NPQ>
+// Query-in-LDS streaming kernel (h = 128 * KB): the query image takes NPQ x KB x sub-tile bytes, the rest of the
+// 160 KiB goes to the waves' rings: as many waves (<= 8) as fit with NT sub-tiles each.
+template <int MODE, int DT, int NPQ, bool AM>
 int launch_stream_bigh(Params& p, hipStream_t st) {
   constexpr int SUB = StreamTraits<DT>::TILE;
   const int KB = p.h / 128;
   const int qbytes = NPQ * KB * SUB;
   const int avail = 160 * 1024 - qbytes;
   int dpwv = env_int("MAXSIM_DPW", 0);
-  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4) ;
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4);
   auto go = [&](auto kern, int waves, int nt) {
     p.dpw = dpwv * waves;
     p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
@@ -90,18 +91,21 @@ int launch_stream_bigh(Params& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
     return check_launch();
   };
-  if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<DT, NPQ, 8, 2>, 8, 2);
-  if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<DT, NPQ, 4, 2>, 4, 2);
-  if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<DT, NPQ, 4, 1>, 4, 1);
+  if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM>, 8, 2);
+  if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM>, 4, 2);
+  if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM>, 4, 1);
   return MAXSIM_ERANGE;
 }
 
+template <int MODE, bool AM>
 int launch_bigh(Params& p, int dt, hipStream_t st) {
   const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;  // query already in the index's 16-bit type: one piece
   switch (dt) {
-    case MAXSIM_F32: return launch_stream_bigh<MAXSIM_F32, 1>(p, st);
-    case MAXSIM_F16: return same16 ? launch_stream_bigh<MAXSIM_F16, 1>(p, st) : launch_stream_bigh<MAXSIM_F16, 2>(p, st);
-    default: return same16 ? launch_stream_bigh<MAXSIM_BF16, 1>(p, st) : launch_stream_bigh<MAXSIM_BF16, 2>(p, st);
+    case MAXSIM_F32: return launch_stream_bigh<MODE, MAXSIM_F32, 1, AM>(p, st);
+    case MAXSIM_F16:
+      return same16 ? launch_stream_bigh<MODE, MAXSIM_F16, 1, AM>(p, st) : launch_stream_bigh<MODE, MAXSIM_F16, 2, AM>(p, st);
+    default:
+      return same16 ? launch_stream_bigh<MODE, MAXSIM_BF16, 1, AM>(p, st) : launch_stream_bigh<MODE, MAXSIM_BF16, 2, AM>(p, st);
   }
 }
 
@@ -138,8 +142,9 @@ const char* maxsim_strerror(int code) {
   }
 }
 
-int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
-                       int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, void* stream) {
+static int score_dense_impl(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
+                            int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, int32_t* argmax,
+                            void* stream) {
   if (nq < 0 || nd < 0 || Lq < 0 || Ld < 0 || h < 0) return MAXSIM_EINVAL;
   if (dtype < MAXSIM_F32 || dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
   if (mask_dtype < MAXSIM_MASK_NONE || mask_dtype > MAXSIM_MASK_U8) return MAXSIM_EINVAL;
@@ -163,11 +168,61 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
   p.q_dtype = dtype;
   p.nq = nq; p.ncand = nd; p.Lq = Lq; p.h = h;
   p.scores = out;
+  p.argmax = argmax;
   p.q_mask = q_mask; p.d_mask = d_mask; p.mask_dtype = mask_dtype;
   p.Ld = Ld;
-  if (dtype == MAXSIM_F32 && h == 128 && Lq <= 32 && p.n_tokens <= 0xffffffffLL)
-    return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st);
+  const bool stream_ok = Lq <= 32 && p.n_tokens <= 0xffffffffLL;
+  if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128) return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st);
+  if (stream_ok && h >= 128 && h <= 1024 && (h & 127) == 0) {
+    int rc = argmax ? launch_bigh<MODE_DENSE, true>(p, dtype, st) : launch_bigh<MODE_DENSE, false>(p, dtype, st);
+    if (rc != MAXSIM_ERANGE) return rc;
+  }
   return launch_generic<MODE_DENSE>(p, dtype, st);
+}
+
+int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
+                       int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, void* stream) {
+  return score_dense_impl(Q, D, q_mask, d_mask, nq, nd, Lq, Ld, h, dtype, mask_dtype, out, nullptr, stream);
+}
+
+int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
+                           int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, int32_t* argmax,
+                           void* stream) {
+  if (!argmax && (int64_t)nq * nd * Lq > 0) return MAXSIM_EINVAL;
+  return score_dense_impl(Q, D, q_mask, d_mask, nq, nd, Lq, Ld, h, dtype, mask_dtype, out, argmax, stream);
+}
+
+int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, const void* d_mask,
+                           const int32_t* argmax, const float* grad_out, int nq, int nd, int Lq, int Ld, int h,
+                           int dtype, int mask_dtype, float* dQ, float* dD, void* stream) {
+  if (nq < 0 || nd < 0 || Lq < 0 || Ld < 0 || h < 0) return MAXSIM_EINVAL;
+  if (dtype < MAXSIM_F32 || dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
+  if (mask_dtype < MAXSIM_MASK_NONE || mask_dtype > MAXSIM_MASK_U8) return MAXSIM_EINVAL;
+  if (h > 1024) return MAXSIM_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t nQ = (int64_t)nq * Lq * h, nD = (int64_t)nd * Ld * h;
+  if (dQ && nQ > 0 && hipMemsetAsync(dQ, 0, nQ * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
+  if (dD && nD > 0 && hipMemsetAsync(dD, 0, nD * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
+  if (nq == 0 || nd == 0 || Lq == 0 || Ld == 0 || h == 0) return MAXSIM_OK;
+  if (!Q || !D || !argmax || !grad_out) return MAXSIM_EINVAL;
+  if (mask_dtype != MAXSIM_MASK_NONE && (!q_mask || !d_mask)) return MAXSIM_EINVAL;
+  if ((int64_t)nq * nd > 0x7fffffffLL || (int64_t)nq * Lq > 0x7fffffffLL) return MAXSIM_ERANGE;
+#define BWD_LAUNCH(DT)                                                                                              \
+  do {                                                                                                              \
+    if (dQ)                                                                                                         \
+      hipLaunchKernelGGL((k_maxsim_bwd_dq<DT>), dim3((unsigned)(nq * Lq)), dim3(256), 0, st, D, q_mask, d_mask,     \
+                         mask_dtype, argmax, grad_out, dQ, nd, Lq, Ld, h);                                          \
+    if (dD)                                                                                                         \
+      hipLaunchKernelGGL((k_maxsim_bwd_dd<DT>), dim3((unsigned)((int64_t)nq * nd)), dim3(256), 0, st, Q, q_mask,    \
+                         d_mask, mask_dtype, argmax, grad_out, dD, nd, Lq, Ld, h);                                  \
+  } while (0)
+  switch (dtype) {
+    case MAXSIM_F32: BWD_LAUNCH(MAXSIM_F32); break;
+    case MAXSIM_F16: BWD_LAUNCH(MAXSIM_F16); break;
+    default: BWD_LAUNCH(MAXSIM_BF16); break;
+  }
+#undef BWD_LAUNCH
+  return check_launch();
 }
 
 int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,
@@ -204,7 +259,7 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
     return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
   }
   if (h > 128 && h <= 1024 && (h & 127) == 0 && Lq >= 1 && Lq <= 32 && n_tokens > 0 && n_tokens <= 0xffffffffLL) {
-    int rc = launch_bigh(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
+    int rc = launch_bigh<MODE_RERANK, false>(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
     if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_RERANK>(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);

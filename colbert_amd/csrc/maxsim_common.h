@@ -36,6 +36,7 @@ struct Params {
   const int64_t* cand;
   int nq, ncand, Lq, h;
   float* scores;
+  int32_t* argmax;  // dense training-form forward only: [nq, nd, Lq] arg-max doc token per query token, or NULL
   // dense only
   const void* q_mask;
   const void* d_mask;
@@ -59,17 +60,17 @@ struct Scalars {
       const int32_t* __restrict__ a_doclens, const int32_t* __restrict__ a_pad_len,                         \
       const void* __restrict__ a_Q, const int32_t* __restrict__ a_q_len, const int64_t* __restrict__ a_cand, \
       float* __restrict__ a_scores, const void* __restrict__ a_q_mask, const void* __restrict__ a_d_mask,   \
-      const maxsim::Scalars sc
+      int32_t* __restrict__ a_argmax, const maxsim::Scalars sc
 #define KARGS_TO_PARAMS                                                                                     \
   maxsim::Params p;                                                                                         \
   p.index = a_index; p.n_tokens = sc.n_tokens; p.tok_offsets = a_tok_offsets; p.doclens = a_doclens;        \
   p.pad_len = a_pad_len; p.n_docs = sc.n_docs; p.Q = a_Q; p.q_len = a_q_len; p.cand = a_cand;               \
   p.nq = sc.nq; p.ncand = sc.ncand; p.Lq = sc.Lq; p.h = sc.h; p.scores = a_scores; p.q_mask = a_q_mask;     \
   p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk;         \
-  p.q_dtype = sc.q_dtype
+  p.q_dtype = sc.q_dtype; p.argmax = a_argmax
 #define KARGS_PASS(p)                                                                                       \
   (p).index, (p).tok_offsets, (p).doclens, (p).pad_len, (p).Q, (p).q_len, (p).cand, (p).scores, (p).q_mask, \
-      (p).d_mask, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
+      (p).d_mask, (p).argmax, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
                                     (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype }
 
 template <int N>

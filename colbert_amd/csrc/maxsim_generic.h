@@ -25,6 +25,7 @@ __global__ void __launch_bounds__(256) k_maxsim_generic(KARGS_DECL) {
 
   for (int mq = wave; mq < p.Lq; mq += 4) {
     float best = NEG_INF;
+    int bestn = 0;
     const bool live = mq < qlen;
     float qs = 1.0f;
     if (masked) qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + mq);
@@ -41,11 +42,18 @@ __global__ void __launch_bounds__(256) k_maxsim_generic(KARGS_DECL) {
           if (masked) { qv *= qs; dv *= ds; }
           acc = fmaf(qv, dv, acc);
         }
-        best = fmaxf(best, acc);
+        if (acc > best) { best = acc; bestn = nn; }  // strict: the first maximal token wins (torch.max)
       }
     }
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) best = fmaxf(best, __shfl_xor(best, o));
+    for (int o = 32; o >= 1; o >>= 1) {
+      const float ob = __shfl_xor(best, o);
+      const int on = __shfl_xor(bestn, o);
+      const bool take = (ob > best) || (ob == best && on < bestn);
+      best = take ? ob : best;
+      bestn = take ? on : bestn;
+    }
+    if (MODE == MODE_DENSE && p.argmax && lane == 0) p.argmax[((int64_t)qi * p.ncand + c) * p.Lq + mq] = bestn;
     if (d.floor0) best = fmaxf(best, 0.0f);
     if (!live) best = 0.0f;  // dropped query token contributes nothing
     if (lane == 0) smax[mq] = best;

@@ -278,6 +278,66 @@ struct Reducer {
   }
 };
 
+// Reduction state that also tracks WHERE each query token's maximum sits (training-form forward: the backward pass
+// routes gradients through the arg-max token, torch.max semantics = first maximal index).  Dense mode only.
+struct ReducerArg {
+  float rmax, myscore;
+  int ridx, jdoc;
+  __device__ __forceinline__ void init() {
+    rmax = NEG_INF;
+    myscore = 0.0f;
+    ridx = 0;
+    jdoc = 0;
+  }
+  // argrow: &argmax[(q * nd + d) * Lq] of the doc that just completed
+  __device__ __forceinline__ void finish_doc(int lane, int32_t* argrow, int Lq) {
+    const uint32_t xb = __float_as_uint(rmax);
+    const auto sv = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+    const auto si = __builtin_amdgcn_permlane32_swap((uint32_t)ridx, (uint32_t)ridx, false, false);
+    const float a = __uint_as_float(sv[0]), b = __uint_as_float(sv[1]);  // lower / upper lane half's running max
+    const int ia = (int)si[0], ib = (int)si[1];
+    const bool take_b = (b > a) || (b == a && ib < ia);
+    float v = take_b ? b : a;
+    const int idx = take_b ? ib : ia;
+    if (lane < Lq) argrow[lane] = idx;
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);
+    const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+                     __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+    myscore = (lane == jdoc) ? sc : myscore;
+    ++jdoc;
+    rmax = NEG_INF;
+    ridx = 0;
+  }
+  // argbase: &argmax[(q * nd + first doc of this wave) * Lq]; docs of a wave are consecutive
+  __device__ __forceinline__ void reduce_tile(const float (&sv)[16], Cursor& C, const DocLanes& dl, int lane,
+                                              int32_t* argbase, int Lq) {
+    const int hh = lane >> 5;
+    int filled = 0;
+    while (filled < 32 && C.valid) {
+      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));
+      const int nbase = C.pos - filled;  // slot s of this tile is token nbase + s of the current doc
+      const uint32_t lo = (uint32_t)(filled - 4 * hh), n_in = (uint32_t)take;
+#pragma unroll
+      for (int v = 0; v < 16; ++v) {
+        const int slot = (v & 3) + 8 * (v >> 2) + 4 * hh;
+        const uint32_t rel = (uint32_t)((v & 3) + 8 * (v >> 2)) - lo;
+        const bool better = (rel < n_in) && (sv[v] > rmax);  // strict: the first maximal token wins
+        rmax = better ? sv[v] : rmax;
+        ridx = better ? nbase + slot : ridx;
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {
+        finish_doc(lane, argbase + (int64_t)C.j * Lq, Lq);
+        C.next_doc(dl);
+      }
+    }
+  }
+};
+
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");

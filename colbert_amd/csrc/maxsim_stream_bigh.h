@@ -1,5 +1,5 @@
-// maxsim_stream_bigh.h -- the streaming MFMA kernel for wide embeddings: h = 128 * KB (e.g. the reference's default
-// dim 768, proj_conf/dense.yaml:8), Lq <= 32, fp32 / fp16 / bf16 token matrix, rerank mode.
+// maxsim_stream_bigh.h -- the streaming MFMA kernel with the query tile in LDS: h = 128 * KB (KB = 1..8, e.g. the
+// reference's default dim 768, proj_conf/dense.yaml:8), Lq <= 32, fp32 / fp16 / bf16 token matrix.
 //
 // Same token-stream structure as maxsim_stream.h (packed 32-row tiles, descriptor lanes, per-wave LDS-DMA ring, DPP
 // reduce), with the contraction split into KB blocks of 128 dims: a "sub-tile" is 32 rows x one 128-dim block (each
@@ -10,17 +10,22 @@
 // pieces: 1 when the query arrives in the index's own 16-bit type (exact), else hi + lo (fp16: lo pre-scaled by
 // 2^11, exact to 2^-22; bf16: 16 significant bits, |error| ~1e-5 per token, inside the 1e-3 tolerance stated for
 // 16-bit inputs); fp32 index: the fp32 query itself (exact f32 MFMA chain).
+//
+// MODE_DENSE (all-pairs BaseModel.score with masks, any of the three dtypes) runs here too: Q * q_mask is folded
+// into the staged query image; D * d_mask multiplies the A operands (fp32, exactly as BaseModel.py:41) or the
+// finished similarities (16-bit inputs; identical for 0/1 masks).  AM = true additionally records each query
+// token's arg-max doc token (training-form forward, see maxsim_backward.h).
 #pragma once
 #include "maxsim_stream.h"
 
 namespace maxsim {
 
-template <int DT, int NPQ, int WAVES, int NT>
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
+  static_assert(!AM || MODE == MODE_DENSE, "arg-max tracking is a dense (training-form) feature");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
-  constexpr int MODE = MODE_RERANK;
   using T = StreamTraits<DT>;
   constexpr int BLKB = T::ROWB;  // bytes of one 128-dim block of a row
   constexpr int SUB = T::TILE;   // bytes of a sub-tile (32 rows x one block) == one query piece block
@@ -39,11 +44,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   char* const qlds = lds;                                   // [NPQ][KB][32 rows][BLKB]
   char* const wlds = lds + NPQ * KB * SUB + wave * (NT * SUB);
   const int r = lane & 31, hh = lane >> 5;
+  const bool masked = MODE == MODE_DENSE && p.mask_dtype != MAXSIM_MASK_NONE;
 
   // ---- stage the query tile in LDS (all waves), B-operand order, swizzled like a doc sub-tile --------------------
   {
     int qlen = p.Lq;
-    if (p.q_len) qlen = min(qlen, p.q_len[qi]);
+    if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
     constexpr int CPB = BLKB / 16;       // 16-byte chunks per row block
     constexpr int EPC = 16 / ESZ;        // elements per chunk
     const int nchunks = KB * 32 * CPB;
@@ -53,9 +59,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       const int kb = idx / (CPB * 32);
       const bool live = n < qlen;
       const int64_t src = ((int64_t)qi * p.Lq + (live ? n : 0)) * p.h + kb * 128 + c * EPC;
+      const float qs = (masked && live) ? load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + n) : 1.0f;
       float q[EPC];
 #pragma unroll
-      for (int j = 0; j < EPC; ++j) q[j] = live ? load_q(p.Q, p.q_dtype, src + j) : 0.0f;
+      for (int j = 0; j < EPC; ++j) {
+        q[j] = live ? load_q(p.Q, p.q_dtype, src + j) : 0.0f;
+        if (MODE == MODE_DENSE) q[j] *= qs;  // Q * q_mask[..., None], BaseModel.py:42
+      }
       char* dst = qlds + kb * SUB + n * BLKB + 16 * (c ^ (n & 15));
       if constexpr (DT == MAXSIM_F32) {
         *(f32x4*)dst = f32x4{q[0], q[1], q[2], q[3]};
@@ -115,8 +125,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   }
 
   Reducer red;
+  ReducerArg reda;
   red.init();
+  reda.init();
+  int32_t* const argbase = AM ? p.argmax + ((int64_t)qi * p.ncand + c_begin) * p.Lq : nullptr;
   int buf = 0, ckb = 0;
+  float mv = 1.0f;  // dense: d_mask value of this lane's row slot in the tile being consumed
   f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
 
   while (nconsumed < nissued) {
@@ -133,12 +147,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
     }
     buf = (buf + 1 == NT) ? 0 : buf + 1;
 
+    if constexpr (MODE == MODE_DENSE) {
+      if (masked && ckb == 0) {  // first block of a tile: look up the tile's 32 mask values (one per lane pair)
+        Cursor Cp = C;
+        const TileMap ct = fill_tile(Cp, dl, r);
+        mv = load_mask(p.d_mask, p.mask_dtype, (int64_t)ct.myrow);
+      }
+    }
+
     const char* qb = qlds + ckb * SUB + rdbase;  // this block's query image, same lane offsets as the doc image
 #pragma unroll
     for (int i = 0; i < NRD; ++i) {
       const int qoff = 16 * ((2 * i + hh) ^ rsw);
       if constexpr (DT == MAXSIM_F32) {
-        const f32x4 av = __builtin_bit_cast(f32x4, a[i]);
+        f32x4 av = __builtin_bit_cast(f32x4, a[i]);
+        if (MODE == MODE_DENSE) av *= mv;  // D * d_mask[..., None], BaseModel.py:41
         const f32x4 bv = *(const f32x4*)(qb + qoff);
 #pragma unroll
         for (int t = 0; t < 4; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc0, 0, 0, 0);
@@ -164,14 +187,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
         else
           sv[v] = acc0[v];
       }
-      red.reduce_tile(sv, C, dl, lane);
+      if constexpr (MODE == MODE_DENSE && DT != MAXSIM_F32) {
+        if (masked) {  // 16-bit inputs: the mask multiplies the finished similarity of its row
+#pragma unroll
+          for (int v = 0; v < 16; ++v) {
+            const int s0 = (v & 3) + 8 * (v >> 2);
+            const float m0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mv), s0));
+            const float m1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mv), s0 + 4));
+            sv[v] *= hh ? m1 : m0;
+          }
+        }
+      }
+      if constexpr (AM) reda.reduce_tile(sv, C, dl, lane, argbase, p.Lq);
+      else red.reduce_tile(sv, C, dl, lane);
       acc0 = (f32x16)(0.0f);
       acc1 = (f32x16)(0.0f);
     }
     ++nconsumed;
   }
-  red.drain(C, dl, lane);
-  if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
+  if constexpr (AM) {
+    if (lane < reda.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = reda.myscore;
+  } else {
+    red.drain(C, dl, lane);
+    if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
+  }
 }
 
 }  // namespace maxsim

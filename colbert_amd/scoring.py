@@ -21,13 +21,7 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def score(Q, D, q_mask, d_mask, *args, **kwargs):
-    """``scores[q, d] = sum_m max_n <Q[q,m]*q_mask[q,m], D[d,n]*d_mask[d,n]>`` on the GPU.
-
-    Same signature, argument meaning and result shape as ``BaseModel.score`` (BaseModel.py:39-46); inputs are
-    borrowed and never mutated; the result is a fresh tensor on the inputs' device whose dtype follows torch's
-    promotion of ``Q * q_mask`` (fp32 for the rerank call, colbert_ranker.py:111-112).  The arithmetic is fp32.
-    """
+def _prepare(Q, D, q_mask, d_mask):
     if Q.dim() != 3 or D.dim() != 3 or q_mask.dim() != 2 or d_mask.dim() != 2:
         raise ValueError("score expects Q[q,m,h], D[d,n,h], q_mask[q,m], d_mask[d,n]")
     if not Q.is_cuda:
@@ -40,11 +34,69 @@ def score(Q, D, q_mask, d_mask, *args, **kwargs):
     dev = Q.device
     out_dtype = torch.promote_types(torch.promote_types(Q.dtype, q_mask.dtype), torch.promote_types(D.dtype, d_mask.dtype))
     cdt = Q.dtype if Q.dtype == D.dtype and Q.dtype in _DT else torch.float32
-    Qc = Q.to(device=dev, dtype=cdt).contiguous()
-    Dc = D.to(device=dev, dtype=cdt).contiguous()
+    Qc = Q.detach().to(device=dev, dtype=cdt).contiguous()
+    Dc = D.detach().to(device=dev, dtype=cdt).contiguous()
     mdt = d_mask.dtype if d_mask.dtype in _MDT else torch.float32
     qm = q_mask.to(device=dev, dtype=mdt).contiguous()
     dm = d_mask.to(device=dev, dtype=mdt).contiguous()
+    return Qc, Dc, qm, dm, cdt, mdt, out_dtype
+
+
+class _MaxSimFn(torch.autograd.Function):
+    """Training form of ``score`` (its second caller: colbert/modeling/colbert_model.py:87-96).  The forward records the
+    arg-max doc token of every (query, doc, query token); the backward routes gradients through it -- the
+    ``[q, d, m, n]`` similarity tensor torch autograd would keep is never materialised."""
+
+    @staticmethod
+    def forward(ctx, Q, D, q_mask, d_mask):
+        Qc, Dc, qm, dm, cdt, mdt, out_dtype = _prepare(Q, D, q_mask, d_mask)
+        nq, Lq, h = Qc.shape
+        nd, Ld, _ = Dc.shape
+        dev = Qc.device
+        out = torch.empty(nq, nd, dtype=torch.float32, device=dev)
+        arg = torch.empty(nq, nd, Lq, dtype=torch.int32, device=dev)
+        with torch.cuda.device(dev):
+            rc = _lib.lib.maxsim_score_dense_fwd(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), nq, nd, Lq, Ld, h, _DT[cdt],
+                                                 _MDT[mdt], _ptr(out), _ptr(arg), _stream(dev))
+        if rc == _lib.EEMPTY:
+            raise IndexError("max(): Expected reduction dim 3 to have non-zero size.")
+        _lib.check(rc, "maxsim_score_dense_fwd")
+        ctx.save_for_backward(Qc, Dc, qm, dm, arg)
+        ctx.meta = (cdt, mdt, Q.dtype, D.dtype)
+        return out if out_dtype == torch.float32 or not out_dtype.is_floating_point else out.to(out_dtype)
+
+    @staticmethod
+    def backward(ctx, g):
+        Qc, Dc, qm, dm, arg = ctx.saved_tensors
+        cdt, mdt, qdt, ddt = ctx.meta
+        nq, Lq, h = Qc.shape
+        nd, Ld, _ = Dc.shape
+        dev = Qc.device
+        g32 = g.to(device=dev, dtype=torch.float32).contiguous()
+        dQ = torch.empty(nq, Lq, h, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        dD = torch.empty(nd, Ld, h, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        with torch.cuda.device(dev):
+            rc = _lib.lib.maxsim_score_dense_bwd(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), _ptr(arg), _ptr(g32), nq, nd, Lq,
+                                                 Ld, h, _DT[cdt], _MDT[mdt], _ptr(dQ), _ptr(dD), _stream(dev))
+        _lib.check(rc, "maxsim_score_dense_bwd")
+        return (None if dQ is None else dQ.to(qdt)), (None if dD is None else dD.to(ddt)), None, None
+
+
+def score(Q, D, q_mask, d_mask, *args, **kwargs):
+    """``scores[q, d] = sum_m max_n <Q[q,m]*q_mask[q,m], D[d,n]*d_mask[d,n]>`` on the GPU.
+
+    Same signature, argument meaning and result shape as ``BaseModel.score`` (BaseModel.py:39-46); inputs are
+    borrowed and never mutated; the result is a fresh tensor on the inputs' device whose dtype follows torch's
+    promotion of ``Q * q_mask`` (fp32 for the rerank call, colbert_ranker.py:111-112).  The arithmetic is fp32.
+    When autograd is recording and Q or D requires grad (the training call, colbert_model.py:90) the result is
+    differentiable: see ``_MaxSimFn``.
+    """
+    if torch.is_grad_enabled() and (Q.requires_grad or D.requires_grad) and Q.size(1) > 0:
+        return _MaxSimFn.apply(Q, D, q_mask, d_mask)
+    Qc, Dc, qm, dm, cdt, mdt, out_dtype = _prepare(Q, D, q_mask, d_mask)
+    nq, Lq, h = Qc.shape
+    nd, Ld, _ = Dc.shape
+    dev = Qc.device
     out = torch.empty(nq, nd, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         rc = _lib.lib.maxsim_score_dense(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), nq, nd, Lq, Ld, h, _DT[cdt],

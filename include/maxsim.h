@@ -6,6 +6,7 @@
  * relative to the reference checkout):
  *
  *   maxsim_score_dense  <- BaseModel.score(Q, D, q_mask, d_mask)      colbert/modeling/BaseModel.py:39-46
+ *   maxsim_score_dense_fwd/_bwd <- the same operator under autograd    colbert/modeling/colbert_model.py:87-96
  *   maxsim_rerank       <- the gather/pad/mask/score body of
  *                          ColbertRanker.rank_forward                 colbert/ranking/colbert_ranker.py:88-118
  *                          (batched over queries: replaces the per-query loop
@@ -68,11 +69,29 @@ const char* maxsim_strerror(int code);
  *   q_mask  [nq, Lq], d_mask [nd, Ld]  element type `mask_dtype` (both), any numeric values
  *   out     [nq, nd] float32 (the arithmetic is fp32 whatever `dtype` is)
  * nq == 0 or nd == 0 is a no-op; Lq == 0 writes zeros; Ld == 0 -> MAXSIM_EEMPTY; h >= 0.
- * Fast path (f32-input MFMA, LDS-DMA staged doc tiles): dtype F32, h == 128, Lq <= 32.
- * Every other shape runs the generic kernel.
+ * Fast paths (MFMA + LDS-DMA streaming): Lq <= 32 and h a multiple of 128 up to 1024, any of the three dtypes
+ * (h == 128 fp32 keeps the query tile in registers).  Every other shape runs the generic kernel.
  */
 int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
                        int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, void* stream);
+
+/*
+ * Training form of the same operator (its second caller: colbert/modeling/colbert_model.py:87-96 differentiates
+ * BaseModel.score through torch autograd and materialises the [q,d,m,n] similarity tensor).  The forward also
+ * records, per (q, d, query token m), the arg-max doc token (torch.max semantics: the first maximal index); the
+ * backward routes the incoming gradient through those tokens:
+ *     dQ[q,m,:] = q_mask[q,m] * sum_d g[q,d] * d_mask[d,i] * D[d,i,:]        i = argmax[q,d,m]
+ *     dD[d,i,:] += d_mask[d,i] * g[q,d] * q_mask[q,m] * Q[q,m,:]
+ *   argmax [nq, nd, Lq] int32;  grad_out [nq, nd] float32;  dQ [nq, Lq, h], dD [nd, Ld, h] float32 (either may be NULL;
+ *   both are fully overwritten).  fp32 accumulation; dD uses float atomics (last bits may vary run to run).
+ * h <= 1024 for the backward.
+ */
+int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
+                           int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, int32_t* argmax,
+                           void* stream);
+int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, const void* d_mask,
+                           const int32_t* argmax, const float* grad_out, int nq, int nd, int Lq, int Ld, int h,
+                           int dtype, int mask_dtype, float* dQ, float* dD, void* stream);
 
 /*
  * Fused ragged rerank, the body of rank_forward (colbert_ranker.py:88-118) for a batch of queries, with the

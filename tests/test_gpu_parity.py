@@ -422,3 +422,51 @@ def test_fp32_fast_mode(ca, golden):
     tp, ts = r.rank_forward(g["Q"], g["pids"].tolist(), depth=10)
     assert tp == g["top10_pids"].tolist()
     np.testing.assert_allclose(ts, g["top10_scores"].numpy(), rtol=0, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# training form: score() under autograd (second caller of the operator, colbert_model.py:87-96)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(nq=3, Lq=32, nd=5, Ld=40, h=128, dtype=torch.float32, masks="01"),
+    dict(nq=2, Lq=16, nd=4, Ld=33, h=256, dtype=torch.float32, masks="float"),
+    dict(nq=4, Lq=32, nd=6, Ld=70, h=768, dtype=torch.bfloat16, masks="01"),
+    dict(nq=2, Lq=20, nd=3, Ld=50, h=128, dtype=torch.float16, masks="01"),
+    dict(nq=2, Lq=5, nd=3, Ld=7, h=24, dtype=torch.float32, masks="01"),          # generic kernel
+    dict(nq=2, Lq=40, nd=2, Ld=9, h=128, dtype=torch.float32, masks="none"),       # Lq > 32: generic kernel
+])
+def test_score_autograd_matches_torch(ca, cfg):
+    from oracle.maxsim_oracle import ref_score
+    gen = torch.Generator().manual_seed(cfg["h"] + cfg["Ld"])
+    Q0 = nrm(gen, cfg["nq"], cfg["Lq"], cfg["h"]).to(cfg["dtype"])
+    D0 = nrm(gen, cfg["nd"], cfg["Ld"], cfg["h"]).to(cfg["dtype"])
+    if cfg["masks"] == "01":
+        qm = (torch.rand(cfg["nq"], cfg["Lq"], generator=gen) > 0.2).long()
+        dm = (torch.rand(cfg["nd"], cfg["Ld"], generator=gen) > 0.3).long()
+    elif cfg["masks"] == "float":
+        qm = torch.rand(cfg["nq"], cfg["Lq"], generator=gen) + 0.1
+        dm = torch.rand(cfg["nd"], cfg["Ld"], generator=gen) + 0.1
+    else:
+        qm, dm = torch.ones(cfg["nq"], cfg["Lq"], dtype=torch.long), torch.ones(cfg["nd"], cfg["Ld"], dtype=torch.long)
+    w = torch.randn(cfg["nq"], cfg["nd"], generator=gen)          # a generic upstream gradient
+    # oracle: torch autograd through the reference's four ops, fp32 on the same (rounded) inputs
+    Qr, Dr = Q0.float().clone().requires_grad_(True), D0.float().clone().requires_grad_(True)
+    out_r = ref_score(Qr, Dr, qm, dm)
+    (out_r * w).sum().backward()
+    # ours
+    Qg, Dg = Q0.detach().cuda().requires_grad_(True), D0.detach().cuda().requires_grad_(True)
+    out_g = ca.score(Qg, Dg, qm.cuda(), dm.cuda())
+    assert out_g.requires_grad
+    (out_g.float() * w.cuda()).sum().backward()
+    tol = ATOL32 if cfg["dtype"] == torch.float32 else 2e-2
+    torch.testing.assert_close(out_g.float().cpu(), out_r.detach(), rtol=0, atol=ATOL32 if cfg["dtype"] == torch.float32 else 5e-2)
+    assert Qg.grad.dtype == cfg["dtype"] and Dg.grad.dtype == cfg["dtype"]
+    torch.testing.assert_close(Qg.grad.float().cpu(), Qr.grad, rtol=0, atol=tol)
+    torch.testing.assert_close(Dg.grad.float().cpu(), Dr.grad, rtol=0, atol=tol)
+    # only D needs grad
+    D2 = D0.detach().cuda().requires_grad_(True)
+    (ca.score(Q0.cuda(), D2, qm.cuda(), dm.cuda()).float() * w.cuda()).sum().backward()
+    torch.testing.assert_close(D2.grad.float().cpu(), Dr.grad, rtol=0, atol=tol)
+    # no_grad: plain forward
+    with torch.no_grad():
+        assert not ca.score(Qg, Dg, qm.cuda(), dm.cuda()).requires_grad
