@@ -201,20 +201,32 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   if (h > 1024) return MAXSIM_ERANGE;
   hipStream_t st = (hipStream_t)stream;
   const int64_t nQ = (int64_t)nq * Lq * h, nD = (int64_t)nd * Ld * h;
-  if (dQ && nQ > 0 && hipMemsetAsync(dQ, 0, nQ * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
-  if (dD && nD > 0 && hipMemsetAsync(dD, 0, nD * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
-  if (nq == 0 || nd == 0 || Lq == 0 || Ld == 0 || h == 0) return MAXSIM_OK;
+  const bool degenerate = nq == 0 || nd == 0 || Lq == 0 || Ld == 0 || h == 0;
+  const bool dd_lds = Ld * 256 <= 150 * 1024;  // the doc's [Ld][64] fp32 slab fits in LDS
+  if (dQ && nQ > 0 && degenerate && hipMemsetAsync(dQ, 0, nQ * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
+  if (dD && nD > 0 && (degenerate || !dd_lds) && hipMemsetAsync(dD, 0, nD * sizeof(float), st) != hipSuccess)
+    return MAXSIM_ELAUNCH;
+  if (degenerate) return MAXSIM_OK;
   if (!Q || !D || !argmax || !grad_out) return MAXSIM_EINVAL;
   if (mask_dtype != MAXSIM_MASK_NONE && (!q_mask || !d_mask)) return MAXSIM_EINVAL;
   if ((int64_t)nq * nd > 0x7fffffffLL || (int64_t)nq * Lq > 0x7fffffffLL) return MAXSIM_ERANGE;
+  const int nchunk = (h + 63) / 64;
+  if (dD && dd_lds && (int64_t)nd * nchunk > 0x7fffffffLL) return MAXSIM_ERANGE;
+  int rc = MAXSIM_OK;
 #define BWD_LAUNCH(DT)                                                                                              \
   do {                                                                                                              \
     if (dQ)                                                                                                         \
       hipLaunchKernelGGL((k_maxsim_bwd_dq<DT>), dim3((unsigned)(nq * Lq)), dim3(256), 0, st, D, q_mask, d_mask,     \
                          mask_dtype, argmax, grad_out, dQ, nd, Lq, Ld, h);                                          \
-    if (dD)                                                                                                         \
-      hipLaunchKernelGGL((k_maxsim_bwd_dd<DT>), dim3((unsigned)((int64_t)nq * nd)), dim3(256), 0, st, Q, q_mask,    \
-                         d_mask, mask_dtype, argmax, grad_out, dD, nd, Lq, Ld, h);                                  \
+    if (dD && dd_lds) {                                                                                             \
+      rc = allow_lds(k_maxsim_bwd_dd_lds<DT>, Ld * 256);                                                            \
+      if (rc == MAXSIM_OK)                                                                                          \
+        hipLaunchKernelGGL((k_maxsim_bwd_dd_lds<DT>), dim3((unsigned)(nd * nchunk)), dim3(1024), Ld * 256, st, Q,   \
+                           q_mask, d_mask, mask_dtype, argmax, grad_out, dD, nq, nd, Lq, Ld, h, nchunk);            \
+    } else if (dD) {                                                                                                \
+      hipLaunchKernelGGL((k_maxsim_bwd_dd_atomic<DT>), dim3((unsigned)((int64_t)nq * nd)), dim3(256), 0, st, Q,     \
+                         q_mask, d_mask, mask_dtype, argmax, grad_out, dD, nd, Lq, Ld, h);                          \
+    }                                                                                                               \
   } while (0)
   switch (dtype) {
     case MAXSIM_F32: BWD_LAUNCH(MAXSIM_F32); break;
@@ -222,6 +234,7 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
     default: BWD_LAUNCH(MAXSIM_BF16); break;
   }
 #undef BWD_LAUNCH
+  if (rc) return rc;
   return check_launch();
 }
 

@@ -83,7 +83,7 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
  *     dQ[q,m,:] = q_mask[q,m] * sum_d g[q,d] * d_mask[d,i] * D[d,i,:]        i = argmax[q,d,m]
  *     dD[d,i,:] += d_mask[d,i] * g[q,d] * q_mask[q,m] * Q[q,m,:]
  *   argmax [nq, nd, Lq] int32;  grad_out [nq, nd] float32;  dQ [nq, Lq, h], dD [nd, Ld, h] float32 (either may be NULL;
- *   both are fully overwritten).  fp32 accumulation; dD uses float atomics (last bits may vary run to run).
+ *   both are fully overwritten).  fp32 accumulation; dD is summed per doc in LDS in a fixed order (reproducible; very long docs fall back to global float atomics).
  * h <= 1024 for the backward.
  */
 int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,

@@ -434,6 +434,8 @@ def test_fp32_fast_mode(ca, golden):
     dict(nq=2, Lq=20, nd=3, Ld=50, h=128, dtype=torch.float16, masks="01"),
     dict(nq=2, Lq=5, nd=3, Ld=7, h=24, dtype=torch.float32, masks="01"),          # generic kernel
     dict(nq=2, Lq=40, nd=2, Ld=9, h=128, dtype=torch.float32, masks="none"),       # Lq > 32: generic kernel
+    dict(nq=70, Lq=3, nd=130, Ld=5, h=200, dtype=torch.float32, masks="01"),       # > 64 docs / items per lane batch
+    dict(nq=1, Lq=2, nd=1, Ld=700, h=64, dtype=torch.float32, masks="none"),       # long doc: atomic dD fallback
 ])
 def test_score_autograd_matches_torch(ca, cfg):
     from oracle.maxsim_oracle import ref_score
