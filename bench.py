@@ -219,6 +219,19 @@ def main():
                          "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if world == 1 and args.workload == "c2":
+            # the reference's online call: ONE query x 1000 candidates through rank_forward (faiss_indexers.py:234),
+            # python lists in and out, host-synchronous -- latency, not throughput
+            Q1 = Q[:1].permute(0, 2, 1).contiguous()               # [1, h, Lq] as ColbertRetriever.search hands it over
+            pids1 = (cands[0, 0] - lo).tolist()
+            lat = []
+            for _ in range(60):
+                t1 = time.perf_counter()
+                ranker.rank_forward(Q1, pids1, depth=TOPK)
+                lat.append(time.perf_counter() - t1)
+            lat = sorted(lat[10:])
+            res["single_query"] = {"call": "rank_forward(Q[1,h,Lq], 1000 pids, depth=100) -> python lists",
+                                   "median_ms": round(lat[len(lat) // 2] * 1e3, 4), "min_ms": round(lat[0] * 1e3, 4)}
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res), flush=True)

@@ -472,3 +472,68 @@ def test_score_autograd_matches_torch(ca, cfg):
     # no_grad: plain forward
     with torch.no_grad():
         assert not ca.score(Qg, Dg, qm.cuda(), dm.cuda()).requires_grad
+
+
+# ------------------------------------------------------------------------------------------------------
+# randomized differential sweep (seeded): every dispatch path against the oracle
+# ------------------------------------------------------------------------------------------------------
+def _sweep_cases():
+    rng = np.random.RandomState(20261004)
+    cases = []
+    for i in range(36):
+        h = int(rng.choice([128, 128, 128, 256, 384, 768, 64, 96, 1024]))
+        dtype = [torch.float32, torch.float16, torch.bfloat16][int(rng.randint(3))]
+        Lq = int(rng.choice([1, 3, 8, 16, 31, 32, 32]))
+        shape = rng.choice(["long", "short", "mixed", "tiny", "multiview"])
+        cases.append((i, h, dtype, Lq, str(shape), bool(rng.rand() < 0.3), bool(rng.rand() < 0.3)))
+    return cases
+
+
+@pytest.mark.parametrize("case", _sweep_cases(), ids=lambda c: f"{c[0]}-h{c[1]}-{str(c[2]).split('.')[-1]}-Lq{c[3]}-{c[4]}")
+def test_randomized_rerank_sweep(ca, case):
+    from oracle.maxsim_oracle import RefRanker
+    i, h, dtype, Lq, shape, use_qlen, fast = case
+    gen = torch.Generator().manual_seed(1000 + i)
+    ndocs = 90
+    if shape == "long":
+        doclens = torch.randint(100, 300, (ndocs,), generator=gen)
+    elif shape == "short":
+        doclens = torch.randint(1, 12, (ndocs,), generator=gen)
+    elif shape == "mixed":
+        doclens = torch.randint(0, 200, (ndocs,), generator=gen)      # includes empty docs
+        doclens[::7] = 0
+    elif shape == "tiny":
+        doclens = torch.randint(1, 3, (ndocs,), generator=gen)
+    else:
+        doclens = torch.full((ndocs,), 8)
+    doclens = doclens.tolist()
+    if sum(doclens) == 0:
+        doclens[0] = 5
+    half = ndocs // 2
+    pdl = [doclens[:half], doclens[half:]]
+    parts = [nrm(gen, max(sum(d), 0), h).to(dtype) for d in pdl]
+    nonempty = [k for k, L in enumerate(doclens) if L > 0]
+    # the reference cannot hold empty docs in a bucket view of stride 0; the oracle index uses the same doclens
+    ref = RefRanker(parts, pdl, dim=h, index_dtype=dtype)
+    kw = dict(fp32_mode="fast") if (fast and dtype == torch.float32 and h == 128) else {}
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=h, index_dtype=dtype, **kw)
+    nq, ncand = 3, 41
+    Q = nrm(gen, nq, Lq, h)
+    cand = torch.stack([torch.randint(0, ndocs, (ncand,), generator=gen) for _ in range(nq)])
+    cand[0, 3] = -1
+    cand[1, 0] = ndocs + 5
+    q_len = torch.randint(1, Lq + 1, (nq,), generator=gen).int() if use_qlen else None
+    sc = r.score_candidates(Q, cand, q_len=q_len).cpu()
+    loose = dtype == torch.bfloat16 and h not in (128,) and h % 128 == 0 and h <= 1024
+    generic16 = dtype != torch.float32 and (h % 128 != 0 or h > 1024)
+    atol = ATOL16 if (loose or generic16) else (1e-5 * 10 if kw else ATOL32)
+    for qi in range(nq):
+        ql = int(q_len[qi]) if use_qlen else Lq
+        for j, pid in enumerate(cand[qi].tolist()):
+            if pid < 0 or pid >= ndocs:
+                assert sc[qi, j] == float("-inf")
+            elif doclens[pid] == 0:
+                assert sc[qi, j] == 0.0
+            else:
+                e = ref.all_scores(Q[qi:qi + 1, :ql].permute(0, 2, 1), [pid])[0]
+                assert abs(sc[qi, j].item() - e.item()) <= atol, (qi, j, pid, sc[qi, j].item(), e.item())
