@@ -45,14 +45,14 @@ int pick_docs_per_wave(const Params& p, int waves) {
   return dpwv;
 }
 
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0>
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>
 int launch_stream_v(Params& p, hipStream_t st) {
   int dpwv = env_int("MAXSIM_DPW", 0);  // tuning knob: docs per wave
   if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
   p.dpw = dpwv * WAVES;
   p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
   const int ldsb = WAVES * NT * StreamTraits<DT>::TILE;
-  auto kern = k_maxsim_stream<MODE, DT, WAVES, NT, ABLATE>;
+  auto kern = k_maxsim_stream<MODE, DT, WAVES, NT, ABLATE, QT>;
   int rc = allow_lds(kern, ldsb);
   if (rc) return rc;
   hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
@@ -64,6 +64,14 @@ int launch_stream_v(Params& p, hipStream_t st) {
 template <int MODE, int DT>
 int launch_stream(Params& p, hipStream_t st) {
   constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
+  if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {  // <= 16 query tokens: the 16-column f32 MFMA form
+    const int v16 = env_int("MAXSIM_VARIANT", 0);
+    if (p.Lq <= 16 && v16 != 4) {
+      if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
+      if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
+      return launch_stream_v<MODE, DT, 4, NT0, 0, 16>(p, st);
+    }
+  }
   switch (env_int("MAXSIM_VARIANT", 0)) {
     case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)
     case 2: return launch_stream_v<MODE, DT, 4, NT0, 2>(p, st);  // no DMA   (timing only, wrong results)

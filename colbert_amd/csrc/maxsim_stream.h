@@ -278,6 +278,71 @@ struct Reducer {
   }
 };
 
+// Reducer for the 16-column accumulator layout of v_mfma_f32_16x16x4_f32 (Lq <= 16): lane = query token (lane & 15)
+// x row quarter g = lane >> 4; sv[4 b + v] = similarity with tile row 16 b + 4 g + v.
+struct Reducer16 {
+  float rmax, myscore;
+  int jdoc;
+  __device__ __forceinline__ void init() {
+    rmax = NEG_INF;
+    myscore = 0.0f;
+    jdoc = 0;
+  }
+  __device__ __forceinline__ void finish_doc(const Cursor& C, int lane) {
+    float sc;
+    if (C.kind == 0) {
+      float v = fmaxf(rmax, __shfl_xor(rmax, 16));
+      const uint32_t xb = __float_as_uint(v);
+      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+      v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      if (C.floor0) v = fmaxf(v, 0.0f);
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      v += dpp_f32<0x141>(v);
+      v += dpp_f32<0x140>(v);  // sum over the 16 query-token lanes of a row
+      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+    } else {
+      sc = C.kind == 1 ? 0.0f : NEG_INF;
+    }
+    myscore = (lane == jdoc) ? sc : myscore;
+    ++jdoc;
+    rmax = NEG_INF;
+  }
+  __device__ __forceinline__ void reduce_tile(const float (&sv)[8], Cursor& C, const DocLanes& dl, int lane) {
+    const int g4 = 4 * (lane >> 4);
+    int filled = 0;
+    while (filled < 32 && C.valid) {
+      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));
+      if (take == 32) {
+        const float t0 = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));
+        const float t1 = fmaxf(fmaxf(sv[4], sv[5]), fmaxf(sv[6], sv[7]));
+        rmax = fmaxf(rmax, fmaxf(t0, t1));
+      } else if (take > 0) {
+        float m = NEG_INF;
+        const uint32_t lo = (uint32_t)(filled - g4), n_in = (uint32_t)take;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const uint32_t rel = (uint32_t)(16 * (v >> 2) + (v & 3)) - lo;
+          m = fmaxf(m, rel < n_in ? sv[v] : NEG_INF);
+        }
+        rmax = fmaxf(rmax, m);
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {
+        finish_doc(C, lane);
+        C.next_doc(dl);
+      }
+    }
+  }
+  __device__ __forceinline__ void drain(Cursor& C, const DocLanes& dl, int lane) {
+    while (C.valid) {
+      finish_doc(C, lane);
+      C.next_doc(dl);
+    }
+  }
+};
+
 // Reduction state that also tracks WHERE each query token's maximum sits (training-form forward: the backward pass
 // routes gradients through the arg-max token, torch.max semantics = first maximal index).  Dense mode only.
 struct ReducerArg {
@@ -338,9 +403,12 @@ struct ReducerArg {
   }
 };
 
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
+// QT = 16: at most 16 query tokens (e.g. the multi-view configs, dense.yaml q_view): fp32 index on
+// v_mfma_f32_16x16x4_f32 -- half the matrix-pipe time of the 32-column form, half the query registers.
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
+  static_assert(QT == 32 || (QT == 16 && DT == MAXSIM_F32 && MODE == MODE_RERANK), "16-column form: fp32 rerank only");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   using T = StreamTraits<DT>;
@@ -369,7 +437,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     const int64_t qoff = ((int64_t)qi * p.Lq + (live ? r : 0)) * 128;
     const float* qrow = (const float*)p.Q + qoff;
     const bool qf32 = p.q_dtype == MAXSIM_F32;  // a 16-bit query is widened element by element (start-up only)
-    if constexpr (DT == MAXSIM_F32) {
+    if constexpr (QT == 16) {
+      // lane (n = lane & 15, kq = lane >> 4) holds Q[n][16 j + 4 kq + t] in qv[j][t], j = 0..7
+      const int n16 = lane & 15, kq = lane >> 4;
+      const bool live16 = n16 < qlen;
+      const int64_t qo = ((int64_t)qi * p.Lq + (live16 ? n16 : 0)) * 128;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, qo + 16 * j + 4 * kq + t);
+        qv[j] = live16 ? v : (f32x4)(0.0f);
+      }
+    } else if constexpr (DT == MAXSIM_F32) {
       float qs = 1.0f;
       if (MODE == MODE_DENSE && live && p.mask_dtype != MAXSIM_MASK_NONE)
         qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + r);
@@ -454,7 +534,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   }
 
   Reducer red;
+  Reducer16 red16;
   red.init();
+  red16.init();
   int buf = 0;
 
   while (nconsumed < nissued) {
@@ -464,9 +546,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     u32x4 a[NRD];
 #pragma unroll
     for (int i = 0; i < NRD; ++i) {
-      // chunk of the row this lane needs for operand i: 16-bit MFMA k-step = 8 consecutive dims per lane half
-      const int c = (DT == F32S) ? (4 * (i >> 1) + 2 * hh + (i & 1)) : (2 * i + hh);
-      a[i] = *(const u32x4*)(tl + 16 * (c ^ rsw));
+      if constexpr (QT == 16) {
+        // operand i = (row block b = i >> 3, k group j = i & 7): row 16 b + (lane & 15), chunk 4 j + (lane >> 4)
+        const int n16 = lane & 15;
+        a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i >> 3) + n16) * ROWB + 16 * ((4 * (i & 7) + (lane >> 4)) ^ n16));
+      } else {
+        // chunk of the row this lane needs for operand i: 16-bit MFMA k-step = 8 consecutive dims per lane half
+        const int c = (DT == F32S) ? (4 * (i >> 1) + 2 * hh + (i & 1)) : (2 * i + hh);
+        a[i] = *(const u32x4*)(tl + 16 * (c ^ rsw));
+      }
     }
     wait_lgkmcnt0();  // operands are in registers: the buffer may be overwritten
     {
@@ -488,6 +576,27 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
     }
 
+    if constexpr (QT == 16) {
+      f32x4 acc[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(a[j]), "v"(a[8 + j]));
+          continue;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[b] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, a[8 * b + j])[t], qv[j][t], acc[b], 0, 0, 0);
+      }
+      float sv8[8];
+#pragma unroll
+      for (int v = 0; v < 8; ++v) sv8[v] = acc[v >> 2][v & 3];
+      red16.reduce_tile(sv8, C, dl, lane);
+      ++nconsumed;
+      continue;
+    }
     float sv[16];
     if constexpr (DT == MAXSIM_F32) {
       f32x16 acc = (f32x16)(0.0f);
@@ -555,8 +664,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     red.reduce_tile(sv, C, dl, lane);
     ++nconsumed;
   }
-  red.drain(C, dl, lane);
-  if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
+  if constexpr (QT == 16) {
+    red16.drain(C, dl, lane);
+    if (lane < red16.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red16.myscore;
+  } else {
+    red.drain(C, dl, lane);
+    if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
+  }
 }
 
 }  // namespace maxsim
