@@ -537,3 +537,35 @@ def test_randomized_rerank_sweep(ca, case):
             else:
                 e = ref.all_scores(Q[qi:qi + 1, :ql].permute(0, 2, 1), [pid])[0]
                 assert abs(sc[qi, j].item() - e.item()) <= atol, (qi, j, pid, sc[qi, j].item(), e.item())
+
+
+# ------------------------------------------------------------------------------------------------------
+# streams and graphs: the library is asynchronous on the caller's stream and capturable into a hipGraph
+# ------------------------------------------------------------------------------------------------------
+def test_side_stream_and_hipgraph_replay(ca):
+    gen = torch.Generator().manual_seed(9)
+    parts, pdl = _random_index(gen, 400, 128, 20, 180, torch.float16)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=128)
+    Q = nrm(gen, 8, 32, 128).cuda()
+    cand = torch.stack([torch.randperm(400, generator=gen)[:200] for _ in range(8)]).cuda()
+    exp_p, exp_s = r.rerank_batch(Q, cand, depth=10)
+    torch.cuda.synchronize()
+    # a non-default stream
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        p1, s1 = r.rerank_batch(Q, cand, depth=10)
+    side.synchronize()
+    assert torch.equal(p1, exp_p) and torch.equal(s1, exp_s)
+    # capture rerank + top-k into a graph, replay it on new inputs written into the static buffers
+    Qs, cs = Q.clone(), cand.clone()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        gp, gs = r.rerank_batch(Qs, cs, depth=10)
+    Q2 = nrm(gen, 8, 32, 128).cuda()
+    cand2 = torch.stack([torch.randperm(400, generator=gen)[:200] for _ in range(8)]).cuda()
+    Qs.copy_(Q2)
+    cs.copy_(cand2)
+    g.replay()
+    torch.cuda.synchronize()
+    e2p, e2s = r.rerank_batch(Q2, cand2, depth=10)
+    assert torch.equal(gp, e2p) and torch.equal(gs, e2s)
