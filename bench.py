@@ -150,15 +150,7 @@ def main():
         doclens = [LD] * ndocs
     ntok = sum(doclens)
     idx = build_index(ntok, H, dev, 1234 + rank, dtype)
-    ranker = colbert_amd.ColbertRanker.__new__(colbert_amd.ColbertRanker)
-    ranker.maxsim_dtype = torch.float32
-    ranker.fp32_mode = args.fp32_mode
-    ranker.device = dev
-    ranker.model = None
-    ranker.pid_offset = rank * ndocs
-    ranker.tensor = idx
-    ranker.num_embeddings = ntok
-    ranker.init_ranker(doclens)
+    ranker = colbert_amd.ColbertRanker.from_device_tensor(idx, doclens, fp32_mode=args.fp32_mode)
     lo, hi = rank * ndocs, (rank + 1) * ndocs
     sharded = ShardedRanker(ranker, lo, hi)
 

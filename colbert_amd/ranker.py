@@ -33,14 +33,13 @@ class ColbertRanker:
     parts / parts_doclens : build from in-memory tensors instead of ``index_path``
     device                : the GPU holding the index
     index_dtype           : storage dtype in HBM (reference: fp16, colbert_ranker.py:62)
-    pid_offset            : global pid of local doc 0 (doc-sharded multi-GPU)
     fp32_mode             : for an fp32 index with dim 128: "exact" (default; f32-input MFMA, an exact fp32 fmaf chain)
                             or "fast" (both operands split into fp16 pieces on the fly, 16-bit MFMA, |error| ~1e-6 on a
                             score, needs |x| < 65504 -- fine for L2-normalised embeddings)
     """
 
     def __init__(self, index_path=None, model=None, dim=None, *, parts=None, parts_doclens=None, device="cuda",
-                 index_dtype=torch.float16, pid_offset=0, fp32_mode="exact"):
+                 index_dtype=torch.float16, fp32_mode="exact"):
         if index_path is not None:
             _, parts_paths, _ = index_io.get_parts(index_path)                # :18
             parts_doclens = index_io.load_doclens(index_path, flatten=False)  # :22
@@ -51,7 +50,6 @@ class ColbertRanker:
         self.parts_doclens = parts_doclens
         self.model = model
         self.device = torch.device(device)
-        self.pid_offset = int(pid_offset)
         assert fp32_mode in ("exact", "fast")
         self.fp32_mode = fp32_mode
         doclens = [int(x) for y in parts_doclens for x in y]                  # flatten, utils.py:133
@@ -66,6 +64,24 @@ class ColbertRanker:
             self.tensor[offset:endpos] = part.to(device=self.device, dtype=index_dtype)
             offset = endpos
         self.init_ranker(doclens)
+
+    @classmethod
+    def from_device_tensor(cls, tensor, doclens, model=None, fp32_mode="exact"):
+        """Adopts an index that already sits in HBM: ``tensor`` [sum(doclens), dim] (fp32/fp16/bf16, contiguous) is
+        used as is, no copy.  (Synthetic benchmarks; shards handed over by another component.)"""
+        self = cls.__new__(cls)
+        assert tensor.is_cuda and tensor.dim() == 2 and tensor.is_contiguous() and tensor.dtype in _DT
+        assert tensor.size(0) == sum(doclens)
+        assert fp32_mode in ("exact", "fast")
+        self.maxsim_dtype = torch.float32
+        self.parts_doclens = [doclens]
+        self.model = model
+        self.device = tensor.device
+        self.fp32_mode = fp32_mode
+        self.num_embeddings = tensor.size(0)
+        self.tensor = tensor
+        self.init_ranker([int(x) for x in doclens])
+        return self
 
     def init_ranker(self, doclens):                                           # :31-43
         pfx = [0] + list(accumulate(doclens))
