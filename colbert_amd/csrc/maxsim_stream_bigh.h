@@ -13,17 +13,128 @@
 //
 // MODE_DENSE (all-pairs BaseModel.score with masks, any of the three dtypes) runs here too: Q * q_mask is folded
 // into the staged query image; D * d_mask multiplies the A operands (fp32, exactly as BaseModel.py:41) or the
-// finished similarities (16-bit inputs; identical for 0/1 masks).  AM = true additionally records each query
-// token's arg-max doc token (training-form forward, see maxsim_backward.h).
+// finished similarities (16-bit inputs; identical for 0/1 masks).  In the all-pairs form every query meets every
+// doc, so a workgroup takes QB queries at once (QB query images in LDS, QB accumulator sets): each doc sub-tile is
+// fetched and read into registers once for all of them.  AM = true additionally records each query token's arg-max
+// doc token (training-form forward, see maxsim_backward.h).
 #pragma once
 #include "maxsim_stream.h"
 
 namespace maxsim {
 
-template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM>
+// Reduction state for QB queries that walk the same documents (dense mode), optionally with arg-max tracking.
+template <int QB, bool AM>
+struct MultiReducer {
+  float rmax[QB], myscore[QB];
+  int ridx[QB];
+  int jdoc;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+      rmax[x] = NEG_INF;
+      myscore[x] = 0.0f;
+      ridx[x] = 0;
+    }
+    jdoc = 0;
+  }
+  // argdoc[x]: &argmax[(query x, this doc) * Lq] (AM only)
+  __device__ __forceinline__ void finish_doc(const Cursor& C, int lane, int32_t* const (&argdoc)[QB], int Lq) {
+#pragma unroll
+    for (int x = 0; x < QB; ++x) {
+      float sc;
+      if (C.kind == 0) {
+        const uint32_t xb = __float_as_uint(rmax[x]);
+        const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+        const float a = __uint_as_float(sw[0]), b = __uint_as_float(sw[1]);
+        float v;
+        if constexpr (AM) {
+          const auto si = __builtin_amdgcn_permlane32_swap((uint32_t)ridx[x], (uint32_t)ridx[x], false, false);
+          const int ia = (int)si[0], ib = (int)si[1];
+          const bool take_b = (b > a) || (b == a && ib < ia);
+          v = take_b ? b : a;
+          if (lane < Lq) argdoc[x][lane] = take_b ? ib : ia;
+        } else {
+          v = fmaxf(a, b);
+        }
+        if (C.floor0) v = fmaxf(v, 0.0f);
+        v += dpp_f32<0xB1>(v);
+        v += dpp_f32<0x4E>(v);
+        v += dpp_f32<0x141>(v);
+        v += dpp_f32<0x140>(v);
+        sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+             __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+      } else {
+        sc = C.kind == 1 ? 0.0f : NEG_INF;
+      }
+      myscore[x] = (lane == jdoc) ? sc : myscore[x];
+      rmax[x] = NEG_INF;
+      ridx[x] = 0;
+    }
+    ++jdoc;
+  }
+  // sv[x][v] = similarity of query x's token (this lane) with tile row (v & 3) + 8 (v >> 2) + 4 (lane >> 5);
+  // argq[x]: &argmax[(query x, first doc of this wave) * Lq]
+  __device__ __forceinline__ void reduce_tile(const float (&sv)[QB][16], Cursor& C, const DocLanes& dl, int lane,
+                                              int32_t* const (&argq)[QB], int Lq) {
+    const int hh = lane >> 5;
+    int filled = 0;
+    while (filled < 32 && C.valid) {
+      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));  // 0: empty doc / padding slot
+      if (!AM && take == 32) {
+#pragma unroll
+        for (int x = 0; x < QB; ++x) {
+          const float t0 = fmaxf(fmaxf(sv[x][0], sv[x][1]), fmaxf(sv[x][2], sv[x][3]));
+          const float t1 = fmaxf(fmaxf(sv[x][4], sv[x][5]), fmaxf(sv[x][6], sv[x][7]));
+          const float t2 = fmaxf(fmaxf(sv[x][8], sv[x][9]), fmaxf(sv[x][10], sv[x][11]));
+          const float t3 = fmaxf(fmaxf(sv[x][12], sv[x][13]), fmaxf(sv[x][14], sv[x][15]));
+          rmax[x] = fmaxf(rmax[x], fmaxf(fmaxf(t0, t1), fmaxf(t2, t3)));
+        }
+      } else if (take > 0) {  // rows [filled, filled + take) only (and every row when arg-max is tracked)
+        const int nbase = C.pos - filled;  // slot s of this tile is token nbase + s of the current doc
+        const uint32_t lo = (uint32_t)(filled - 4 * hh), n_in = (uint32_t)take;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          const uint32_t rel = (uint32_t)((v & 3) + 8 * (v >> 2)) - lo;
+          const bool in = rel < n_in;
+#pragma unroll
+          for (int x = 0; x < QB; ++x) {
+            if constexpr (AM) {
+              const bool better = in && (sv[x][v] > rmax[x]);  // strict: the first maximal token wins
+              rmax[x] = better ? sv[x][v] : rmax[x];
+              ridx[x] = better ? nbase + (v & 3) + 8 * (v >> 2) + 4 * hh : ridx[x];
+            } else {
+              rmax[x] = fmaxf(rmax[x], in ? sv[x][v] : NEG_INF);
+            }
+          }
+        }
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {  // doc complete (empty docs / padding slots are scored on the spot)
+        int32_t* argdoc[QB];
+#pragma unroll
+        for (int x = 0; x < QB; ++x) argdoc[x] = AM ? argq[x] + (int64_t)C.j * Lq : nullptr;
+        finish_doc(C, lane, argdoc, Lq);
+        C.next_doc(dl);
+      }
+    }
+  }
+  __device__ __forceinline__ void drain(Cursor& C, const DocLanes& dl, int lane, int32_t* const (&argq)[QB], int Lq) {
+    while (C.valid) {  // trailing empty docs / padding slots
+      int32_t* argdoc[QB];
+#pragma unroll
+      for (int x = 0; x < QB; ++x) argdoc[x] = AM ? argq[x] + (int64_t)C.j * Lq : nullptr;
+      finish_doc(C, lane, argdoc, Lq);
+      C.next_doc(dl);
+    }
+  }
+};
+
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
   static_assert(!AM || MODE == MODE_DENSE, "arg-max tracking is a dense (training-form) feature");
+  static_assert(QB == 1 || MODE == MODE_DENSE, "several queries share documents only in the all-pairs form");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   using T = StreamTraits<DT>;
@@ -35,28 +146,33 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   const uint32_t rowbytes = (uint32_t)p.h * ESZ;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int qi = blockIdx.x / p.nchunk;
-  const int chunk = blockIdx.x - qi * p.nchunk;
+  const int qblk = blockIdx.x / p.nchunk;
+  const int chunk = blockIdx.x - qblk * p.nchunk;
+  const int q0 = qblk * QB;  // first query of this workgroup; queries past nq - 1 are clamped and not written
   const int dpwv = p.dpw / WAVES;
   const int c_begin = chunk * p.dpw + wave * dpwv;
   const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
-  const DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, lane);
-  char* const qlds = lds;                                   // [NPQ][KB][32 rows][BLKB]
-  char* const wlds = lds + NPQ * KB * SUB + wave * (NT * SUB);
+  const DocLanes dl = load_doc_lanes<MODE>(p, q0, c_begin, ndoc, lane);
+  const int qimg = NPQ * KB * SUB;                          // one query's image: [NPQ][KB][32 rows][BLKB]
+  char* const qlds = lds;
+  char* const wlds = lds + QB * qimg + wave * (NT * SUB);
   const int r = lane & 31, hh = lane >> 5;
   const bool masked = MODE == MODE_DENSE && p.mask_dtype != MAXSIM_MASK_NONE;
 
-  // ---- stage the query tile in LDS (all waves), B-operand order, swizzled like a doc sub-tile --------------------
+  // ---- stage the query tiles in LDS (all waves), B-operand order, swizzled like a doc sub-tile -------------------
   {
-    int qlen = p.Lq;
-    if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
     constexpr int CPB = BLKB / 16;       // 16-byte chunks per row block
     constexpr int EPC = 16 / ESZ;        // elements per chunk
     const int nchunks = KB * 32 * CPB;
-    for (int idx = threadIdx.x; idx < nchunks; idx += WAVES * 64) {
-      const int c = idx % CPB;
-      const int n = (idx / CPB) & 31;
-      const int kb = idx / (CPB * 32);
+    for (int idx = threadIdx.x; idx < QB * nchunks; idx += WAVES * 64) {
+      const int x = idx / nchunks;
+      const int rem = idx - x * nchunks;
+      const int c = rem % CPB;
+      const int n = (rem / CPB) & 31;
+      const int kb = rem / (CPB * 32);
+      const int qi = min(q0 + x, p.nq - 1);
+      int qlen = p.Lq;
+      if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
       const bool live = n < qlen;
       const int64_t src = ((int64_t)qi * p.Lq + (live ? n : 0)) * p.h + kb * 128 + c * EPC;
       const float qs = (masked && live) ? load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + n) : 1.0f;
@@ -66,7 +182,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
         q[j] = live ? load_q(p.Q, p.q_dtype, src + j) : 0.0f;
         if (MODE == MODE_DENSE) q[j] *= qs;  // Q * q_mask[..., None], BaseModel.py:42
       }
-      char* dst = qlds + kb * SUB + n * BLKB + 16 * (c ^ (n & 15));
+      char* dst = qlds + x * qimg + kb * SUB + n * BLKB + 16 * (c ^ (n & 15));
       if constexpr (DT == MAXSIM_F32) {
         *(f32x4*)dst = f32x4{q[0], q[1], q[2], q[3]};
       } else {
@@ -87,13 +203,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
         for (int k = 0; k < NPQ; ++k) {
           u32x4 w;
 #pragma unroll
-          for (int x = 0; x < 4; ++x) w[x] = (uint32_t)pc[k][2 * x] | ((uint32_t)pc[k][2 * x + 1] << 16);
+          for (int y = 0; y < 4; ++y) w[y] = (uint32_t)pc[k][2 * y] | ((uint32_t)pc[k][2 * y + 1] << 16);
           *(u32x4*)(dst + k * KB * SUB) = w;
         }
       }
     }
   }
-  __syncthreads();  // the only workgroup barrier: the query image is read-only from here on
+  __syncthreads();  // the only workgroup barrier: the query images are read-only from here on
 
   const int rsw = r & 15;
   const int rdbase = r * BLKB;
@@ -124,14 +240,19 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
     prev_issued = ok;
   }
 
-  Reducer red;
-  ReducerArg reda;
+  MultiReducer<QB, AM> red;
   red.init();
-  reda.init();
-  int32_t* const argbase = AM ? p.argmax + ((int64_t)qi * p.ncand + c_begin) * p.Lq : nullptr;
+  int32_t* argq[QB];
+#pragma unroll
+  for (int x = 0; x < QB; ++x)
+    argq[x] = AM ? p.argmax + ((int64_t)min(q0 + x, p.nq - 1) * p.ncand + c_begin) * p.Lq : nullptr;
   int buf = 0, ckb = 0;
   float mv = 1.0f;  // dense: d_mask value of this lane's row slot in the tile being consumed
-  f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
+  f32x16 acc0[QB], acc1[NPQ == 2 ? QB : 1];
+#pragma unroll
+  for (int x = 0; x < QB; ++x) acc0[x] = (f32x16)(0.0f);
+#pragma unroll
+  for (int x = 0; x < (NPQ == 2 ? QB : 1); ++x) acc1[x] = (f32x16)(0.0f);
 
   while (nconsumed < nissued) {
     if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
@@ -153,40 +274,50 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
         const TileMap ct = fill_tile(Cp, dl, r);
         mv = load_mask(p.d_mask, p.mask_dtype, (int64_t)ct.myrow);
       }
+      if constexpr (DT == MAXSIM_F32) {
+        if (masked) {  // D * d_mask[..., None], BaseModel.py:41
+#pragma unroll
+          for (int i = 0; i < NRD; ++i) a[i] = __builtin_bit_cast(u32x4, __builtin_bit_cast(f32x4, a[i]) * mv);
+        }
+      }
     }
 
-    const char* qb = qlds + ckb * SUB + rdbase;  // this block's query image, same lane offsets as the doc image
 #pragma unroll
-    for (int i = 0; i < NRD; ++i) {
-      const int qoff = 16 * ((2 * i + hh) ^ rsw);
-      if constexpr (DT == MAXSIM_F32) {
-        f32x4 av = __builtin_bit_cast(f32x4, a[i]);
-        if (MODE == MODE_DENSE) av *= mv;  // D * d_mask[..., None], BaseModel.py:41
-        const f32x4 bv = *(const f32x4*)(qb + qoff);
+    for (int x = 0; x < QB; ++x) {
+      const char* qb = qlds + x * qimg + ckb * SUB + rdbase;  // query x, this block: same lane offsets as the doc image
 #pragma unroll
-        for (int t = 0; t < 4; ++t) acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc0, 0, 0, 0);
-      } else if constexpr (DT == MAXSIM_F16) {
-        const f16x8 av = __builtin_bit_cast(f16x8, a[i]);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + qoff), acc0, 0, 0, 0);
-        if constexpr (NPQ == 2)
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + KB * SUB + qoff), acc1, 0, 0, 0);
-      } else {
-        const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
-        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + qoff), acc0, 0, 0, 0);
-        if constexpr (NPQ == 2)
-          acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + KB * SUB + qoff), acc1, 0, 0, 0);
+      for (int i = 0; i < NRD; ++i) {
+        const int qoff = 16 * ((2 * i + hh) ^ rsw);
+        if constexpr (DT == MAXSIM_F32) {
+          const f32x4 av = __builtin_bit_cast(f32x4, a[i]);
+          const f32x4 bv = *(const f32x4*)(qb + qoff);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) acc0[x] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[t], acc0[x], 0, 0, 0);
+        } else if constexpr (DT == MAXSIM_F16) {
+          const f16x8 av = __builtin_bit_cast(f16x8, a[i]);
+          acc0[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + qoff), acc0[x], 0, 0, 0);
+          if constexpr (NPQ == 2)
+            acc1[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + KB * SUB + qoff), acc1[x], 0, 0, 0);
+        } else {
+          const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
+          acc0[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + qoff), acc0[x], 0, 0, 0);
+          if constexpr (NPQ == 2)
+            acc1[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + KB * SUB + qoff), acc1[x], 0, 0, 0);
+        }
       }
     }
     ckb = (ckb + 1 == KB) ? 0 : ckb + 1;
     if (ckb == 0) {  // last block of the tile: similarities are complete
-      float sv[16];
+      float sv[QB][16];
 #pragma unroll
-      for (int v = 0; v < 16; ++v) {
-        if constexpr (NPQ == 2)
-          sv[v] = (DT == MAXSIM_F16) ? fmaf(acc1[v], 1.0f / 2048.0f, acc0[v]) : (acc0[v] + acc1[v]);
-        else
-          sv[v] = acc0[v];
-      }
+      for (int x = 0; x < QB; ++x)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+          if constexpr (NPQ == 2)
+            sv[x][v] = (DT == MAXSIM_F16) ? fmaf(acc1[x][v], 1.0f / 2048.0f, acc0[x][v]) : (acc0[x][v] + acc1[x][v]);
+          else
+            sv[x][v] = acc0[x][v];
+        }
       if constexpr (MODE == MODE_DENSE && DT != MAXSIM_F32) {
         if (masked) {  // 16-bit inputs: the mask multiplies the finished similarity of its row
 #pragma unroll
@@ -194,23 +325,23 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
             const int s0 = (v & 3) + 8 * (v >> 2);
             const float m0 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mv), s0));
             const float m1 = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(mv), s0 + 4));
-            sv[v] *= hh ? m1 : m0;
+#pragma unroll
+            for (int x = 0; x < QB; ++x) sv[x][v] *= hh ? m1 : m0;
           }
         }
       }
-      if constexpr (AM) reda.reduce_tile(sv, C, dl, lane, argbase, p.Lq);
-      else red.reduce_tile(sv, C, dl, lane);
-      acc0 = (f32x16)(0.0f);
-      acc1 = (f32x16)(0.0f);
+      red.reduce_tile(sv, C, dl, lane, argq, p.Lq);
+#pragma unroll
+      for (int x = 0; x < QB; ++x) acc0[x] = (f32x16)(0.0f);
+#pragma unroll
+      for (int x = 0; x < (NPQ == 2 ? QB : 1); ++x) acc1[x] = (f32x16)(0.0f);
     }
     ++nconsumed;
   }
-  if constexpr (AM) {
-    if (lane < reda.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = reda.myscore;
-  } else {
-    red.drain(C, dl, lane);
-    if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
-  }
+  red.drain(C, dl, lane, argq, p.Lq);
+#pragma unroll
+  for (int x = 0; x < QB; ++x)
+    if (lane < red.jdoc && q0 + x < p.nq) p.scores[(int64_t)(q0 + x) * p.ncand + c_begin + lane] = red.myscore[x];
 }
 
 }  // namespace maxsim
