@@ -111,7 +111,8 @@ def main():
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
     ap.add_argument("--fp32-mode", default="exact", choices=["exact", "fast"],
                     help="fp32 index only: exact f32 MFMA (default) or the split-fp16 fast mode")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the host-side legs (cpu_baseline and the single-query latency probe): profiling runs")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still initialise RCCL (world 1) and run the all_gather + merge leg")
     args = ap.parse_args()
@@ -232,7 +233,7 @@ def main():
                          "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
-        if world == 1 and args.workload == "c2":
+        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             # the reference's online call: ONE query x 1000 candidates through rank_forward (faiss_indexers.py:234),
             # python lists in and out, host-synchronous -- latency, not throughput
             Q1 = Q[:1].permute(0, 2, 1).contiguous()               # [1, h, Lq] as ColbertRetriever.search hands it over
