@@ -37,6 +37,19 @@ def main():
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
             for r in rows[:12]:
                 w.writerow([short(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
+    # steady-state average of the maxsim kernels from the per-dispatch trace (first 3 launches = bench warm-up dropped)
+    steady = {}
+    kt = one(os.path.join(trace, "**", "*kernel_trace.csv"))
+    if kt:
+        per = {}
+        for r in csv.DictReader(open(kt)):
+            if "k_maxsim" in r["Kernel_Name"]:
+                per.setdefault(short(r["Kernel_Name"]).split("(")[0], []).append(
+                    (int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
+        for k, v in per.items():
+            d = [x[1] for x in sorted(v)][3:]
+            if d:
+                steady[k] = {"launches": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
     out = {}
     for key, flag in (("fetch", "--fetch"), ("write", "--write"), ("sq", "--sq")):
         d = opts.get(flag)
@@ -68,6 +81,8 @@ def main():
             # busy cycles summed over 1024 SIMDs / (cycles per XCD-summed GUI_ACTIVE / 8)
             s["mfma_util(SQ_VALU_MFMA_BUSY_CYCLES/1024 / (GRBM_GUI_ACTIVE/8))"] = (s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (s["GRBM_GUI_ACTIVE"] / 8)
         summ[k] = s
+    for k, v in steady.items():
+        summ.setdefault(k, {})["kernel_trace_steady(after 3 warm-up launches)"] = v
     with open(f"profiles/{tag}_pmc.json", "w") as f:
         json.dump(summ, f, indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1, sort_keys=True))

@@ -1,5 +1,8 @@
 #!/bin/bash
+# On the GPU box: A/B sweeps through bench.py (kernel ms and algorithmic GB/s per configuration).
+# usage: tools/sweep.sh            -> every workload, default kernels
+#        MAXSIM_VARIANT=1|2 ...    -> ablation builds of the h=128 stream kernel (DESIGN.md "Tuning knobs")
 P='import sys,json; r=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(r["value"], r["roofline"]["kernel_ms"], r["roofline"]["achieved"])'
-for v in 4 0 1 2; do echo "c4 variant=$v (4 = 32-column form)"; MAXSIM_VARIANT=$v python bench.py --workload c4 --steps 20 --warmup 3 --no-cpu-baseline | python -c "$P"; done
-for v in 4 0; do echo "c4 --lq 16 variant=$v"; MAXSIM_VARIANT=$v python bench.py --workload c4 --lq 16 --steps 20 --warmup 3 --no-cpu-baseline | python -c "$P"; done
-for v in 4 0; do echo "c2 --lq 16 variant=$v"; MAXSIM_VARIANT=$v python bench.py --workload c2 --lq 16 --ndocs 400000 --steps 20 --warmup 3 --no-cpu-baseline | python -c "$P"; done
+for wl in "c2" "c2 --index-dtype fp16" "c2 --fp32-mode fast" "ragged" "c4" "c4 --index-dtype fp16" "c5"; do
+  echo "workload=$wl"; python bench.py --workload $wl --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "$P"
+done
