@@ -424,6 +424,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   char* const wlds = lds + wave * (NT * TILE);
   const int r = lane & 31, hh = lane >> 5;
 
+  // ---- per-lane constants ------------------------------------------------------------------------------------
+  const int rsw = r & 15;
+  const int rdbase = r * ROWB;
+  const char* const tok = (const char*)p.index;
+
+  Cursor F, C;
+  F.init(dl, ndoc);
+  C = F;
+
+  auto issue_tile = [&](int buf, const TileMap& t) __attribute__((always_inline)) {
+    if (ABLATE == 2) return;
+    issue_rows<NDMA, RPD, LPR>(tok, (uint32_t)ROWB, 0u, wlds + buf * TILE, t, lane);
+  };
+
+  // ---- prologue: up to NT tiles in flight (issued BEFORE the query tile is loaded: its latency overlaps the
+  //      first fetch) -----------------------------------------------------------------------
+  int nissued = 0, nconsumed = 0;
+  bool prev_issued = false;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const TileMap t = fill_tile(F, dl, r);
+    if (t.kind != 0) {
+      issue_tile(j, t);
+      ++nissued;
+    }
+    prev_issued = t.kind != 0;
+  }
+
   // ---- query tile -> registers in MFMA B layout --------------------------------------------------------------
   // fp32: lane (n, hh) holds Q[n][32 s + 8 u + 4 hh + t]   in qv[4 s + u][t]
   // 16b : lane (n, hh) holds Q[n][16 i + 8 hh + j], j=0..7 in qp[piece][i] (packed pairs)
@@ -504,33 +532,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
           for (int w = 0; w < 4; ++w) qp[k][i][w] = (uint32_t)pc[k][2 * w] | ((uint32_t)pc[k][2 * w + 1] << 16);
       }
     }
-  }
-
-  // ---- per-lane constants ------------------------------------------------------------------------------------
-  const int rsw = r & 15;
-  const int rdbase = r * ROWB;
-  const char* const tok = (const char*)p.index;
-
-  Cursor F, C;
-  F.init(dl, ndoc);
-  C = F;
-
-  auto issue_tile = [&](int buf, const TileMap& t) __attribute__((always_inline)) {
-    if (ABLATE == 2) return;
-    issue_rows<NDMA, RPD, LPR>(tok, (uint32_t)ROWB, 0u, wlds + buf * TILE, t, lane);
-  };
-
-  // ---- prologue: up to NT tiles in flight -----------------------------------------------------------------------
-  int nissued = 0, nconsumed = 0;
-  bool prev_issued = false;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const TileMap t = fill_tile(F, dl, r);
-    if (t.kind != 0) {
-      issue_tile(j, t);
-      ++nissued;
-    }
-    prev_issued = t.kind != 0;
   }
 
   Reducer red;

@@ -159,6 +159,36 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   const int r = lane & 31, hh = lane >> 5;
   const bool masked = MODE == MODE_DENSE && p.mask_dtype != MAXSIM_MASK_NONE;
 
+  const int rsw = r & 15;
+  const int rdbase = r * BLKB;
+  const char* const tok = (const char*)p.index;
+
+  Cursor F, C;
+  F.init(dl, ndoc);
+  C = F;
+
+  // fetch side: the tile being fetched block by block
+  TileMap ft;
+  ft.myrow = 0; ft.base0 = 0; ft.base1 = 0; ft.split = 32; ft.kind = 0;
+  int fkb = 0;
+  auto fetch_next = [&](int buf) __attribute__((always_inline)) -> bool {
+    if (fkb == 0) ft = fill_tile(F, dl, r);
+    if (ft.kind == 0) return false;
+    issue_rows<NDMA, RPD, LPR>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
+    fkb = (fkb + 1 == KB) ? 0 : fkb + 1;
+    return true;
+  };
+
+  // prologue fetches are issued BEFORE the query images are staged: the staging latency overlaps the first fetch
+  int nissued = 0, nconsumed = 0;
+  bool prev_issued = false;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const bool ok = fetch_next(j);
+    nissued += ok ? 1 : 0;
+    prev_issued = ok;
+  }
+
   // ---- stage the query tiles in LDS (all waves), B-operand order, swizzled like a doc sub-tile -------------------
   {
     constexpr int CPB = BLKB / 16;       // 16-byte chunks per row block
@@ -210,35 +240,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
     }
   }
   __syncthreads();  // the only workgroup barrier: the query images are read-only from here on
-
-  const int rsw = r & 15;
-  const int rdbase = r * BLKB;
-  const char* const tok = (const char*)p.index;
-
-  Cursor F, C;
-  F.init(dl, ndoc);
-  C = F;
-
-  // fetch side: the tile being fetched block by block
-  TileMap ft;
-  ft.myrow = 0; ft.base0 = 0; ft.base1 = 0; ft.split = 32; ft.kind = 0;
-  int fkb = 0;
-  auto fetch_next = [&](int buf) __attribute__((always_inline)) -> bool {
-    if (fkb == 0) ft = fill_tile(F, dl, r);
-    if (ft.kind == 0) return false;
-    issue_rows<NDMA, RPD, LPR>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
-    fkb = (fkb + 1 == KB) ? 0 : fkb + 1;
-    return true;
-  };
-
-  int nissued = 0, nconsumed = 0;
-  bool prev_issued = false;
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const bool ok = fetch_next(j);
-    nissued += ok ? 1 : 0;
-    prev_issued = ok;
-  }
 
   MultiReducer<QB, AM> red;
   red.init();
