@@ -66,7 +66,7 @@ int launch_stream(Params& p, hipStream_t st) {
   constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
   if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {  // <= 16 query tokens: the 16-column f32 MFMA form
     const int v16 = env_int("MAXSIM_VARIANT", 0);
-    if (p.Lq <= 16 && v16 != 4) {
+    if (p.Lq <= 16 && v16 != 4) {  // (Lq <= 16 implies a single query slice)
       if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
       if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
       return launch_stream_v<MODE, DT, 4, NT0, 0, 16>(p, st);
@@ -138,6 +138,22 @@ int launch_bigh(Params& p, int dt, hipStream_t st) {
   }
 }
 
+// Queries longer than 32 tokens: score(Q) = sum over 32-token slices of score(slice) (the sum over query tokens
+// is additive), one launch per slice, the later ones accumulating into `scores`.
+template <typename F>
+int for_query_slices(Params& p, F&& launch) {
+  for (int t0 = 0; t0 < p.Lq; t0 += 32) {
+    p.q_tok0 = t0;
+    p.accum = t0 > 0;
+    int rc = launch();
+    if (rc != MAXSIM_OK) return rc;
+  }
+  p.q_tok0 = 0;
+  p.accum = 0;
+  return MAXSIM_OK;
+}
+constexpr int MAX_LQ_SLICED = 1024;
+
 template <int MODE>
 int launch_generic(Params& p, int dt, hipStream_t st) {
   const dim3 grid((unsigned)((int64_t)p.nq * p.ncand)), block(256);
@@ -200,10 +216,12 @@ static int score_dense_impl(const void* Q, const void* D, const void* q_mask, co
   p.argmax = argmax;
   p.q_mask = q_mask; p.d_mask = d_mask; p.mask_dtype = mask_dtype;
   p.Ld = Ld;
-  const bool stream_ok = Lq <= 32 && p.n_tokens <= 0xffffffffLL;
-  if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128) return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st);
+  const bool stream_ok = (Lq <= 32 || (!argmax && Lq <= MAX_LQ_SLICED)) && p.n_tokens <= 0xffffffffLL;
+  if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128)
+    return for_query_slices(p, [&] { return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st); });
   if (stream_ok && h >= 128 && h <= 1024 && (h & 127) == 0) {
-    int rc = argmax ? launch_bigh<MODE_DENSE, true>(p, dtype, st) : launch_bigh<MODE_DENSE, false>(p, dtype, st);
+    int rc = argmax ? launch_bigh<MODE_DENSE, true>(p, dtype, st)
+                    : for_query_slices(p, [&] { return launch_bigh<MODE_DENSE, false>(p, dtype, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_DENSE>(p, dtype, st);
@@ -294,14 +312,18 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
   p.nq = nq; p.ncand = ncand; p.Lq = Lq; p.h = h;
   p.scores = scores;
   p.mask_dtype = MAXSIM_MASK_NONE;
-  if (h == 128 && Lq >= 1 && Lq <= 32 && n_tokens > 0 && n_tokens <= 0xffffffffLL) {
-    if (index_dtype == MAXSIM_F32) return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
-    if (index_dtype == MAXSIM_F32_FAST) return launch_stream<MODE_RERANK, MAXSIM_F32_FAST>(p, st);
-    if (index_dtype == MAXSIM_F16) return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
-    return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
+  const bool stream_ok = Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
+  if (h == 128 && stream_ok) {
+    return for_query_slices(p, [&] {
+      if (index_dtype == MAXSIM_F32) return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
+      if (index_dtype == MAXSIM_F32_FAST) return launch_stream<MODE_RERANK, MAXSIM_F32_FAST>(p, st);
+      if (index_dtype == MAXSIM_F16) return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
+      return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
+    });
   }
-  if (h > 128 && h <= 1024 && (h & 127) == 0 && Lq >= 1 && Lq <= 32 && n_tokens > 0 && n_tokens <= 0xffffffffLL) {
-    int rc = launch_bigh<MODE_RERANK, false>(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
+  if (h > 128 && h <= 1024 && (h & 127) == 0 && stream_ok) {
+    const int dt = index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype;
+    int rc = for_query_slices(p, [&] { return launch_bigh<MODE_RERANK, false>(p, dt, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_RERANK>(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);

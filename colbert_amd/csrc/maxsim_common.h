@@ -32,6 +32,8 @@ struct Params {
   // queries
   const void* Q;
   int q_dtype;  // element type of Q (rerank: MAXSIM_F32 / F16 / BF16; dense: same as the token matrix)
+  int q_tok0;   // first query token handled by this launch (queries longer than 32 tokens take one launch per 32)
+  int accum;    // 1: add this launch's partial sums to `scores` (passes after the first)
   const int32_t* q_len;
   const int64_t* cand;
   int nq, ncand, Lq, h;
@@ -53,7 +55,7 @@ struct Params {
 // stream and drain it at every document boundary.
 struct Scalars {
   int64_t n_tokens, n_docs;
-  int nq, ncand, Lq, h, mask_dtype, Ld, dpw, nchunk, q_dtype;
+  int nq, ncand, Lq, h, mask_dtype, Ld, dpw, nchunk, q_dtype, q_tok0, accum;
 };
 #define KARGS_DECL                                                                                         \
   const void* __restrict__ a_index, const int64_t* __restrict__ a_tok_offsets,                              \
@@ -67,11 +69,11 @@ struct Scalars {
   p.pad_len = a_pad_len; p.n_docs = sc.n_docs; p.Q = a_Q; p.q_len = a_q_len; p.cand = a_cand;               \
   p.nq = sc.nq; p.ncand = sc.ncand; p.Lq = sc.Lq; p.h = sc.h; p.scores = a_scores; p.q_mask = a_q_mask;     \
   p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk;         \
-  p.q_dtype = sc.q_dtype; p.argmax = a_argmax
+  p.q_dtype = sc.q_dtype; p.argmax = a_argmax; p.q_tok0 = sc.q_tok0; p.accum = sc.accum
 #define KARGS_PASS(p)                                                                                       \
   (p).index, (p).tok_offsets, (p).doclens, (p).pad_len, (p).Q, (p).q_len, (p).cand, (p).scores, (p).q_mask, \
       (p).d_mask, (p).argmax, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
-                                    (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype }
+                                    (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype, (p).q_tok0, (p).accum }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

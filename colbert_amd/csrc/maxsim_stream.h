@@ -461,15 +461,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   {
     int qlen = p.Lq;
     if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
-    const bool live = r < qlen;
-    const int64_t qoff = ((int64_t)qi * p.Lq + (live ? r : 0)) * 128;
+    const int qtok = p.q_tok0 + r;  // this lane's query token (queries longer than 32 tokens: one launch per 32)
+    const bool live = qtok < qlen;
+    const int64_t qoff = ((int64_t)qi * p.Lq + (live ? qtok : 0)) * 128;
     const float* qrow = (const float*)p.Q + qoff;
     const bool qf32 = p.q_dtype == MAXSIM_F32;  // a 16-bit query is widened element by element (start-up only)
     if constexpr (QT == 16) {
       // lane (n = lane & 15, kq = lane >> 4) holds Q[n][16 j + 4 kq + t] in qv[j][t], j = 0..7
       const int n16 = lane & 15, kq = lane >> 4;
-      const bool live16 = n16 < qlen;
-      const int64_t qo = ((int64_t)qi * p.Lq + (live16 ? n16 : 0)) * 128;
+      const bool live16 = p.q_tok0 + n16 < qlen;
+      const int64_t qo = ((int64_t)qi * p.Lq + (live16 ? p.q_tok0 + n16 : 0)) * 128;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         f32x4 v;
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     } else if constexpr (DT == MAXSIM_F32) {
       float qs = 1.0f;
       if (MODE == MODE_DENSE && live && p.mask_dtype != MAXSIM_MASK_NONE)
-        qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + r);
+        qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + qtok);
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int e0 = 4 * hh + 32 * (i >> 2) + 8 * (i & 3);
@@ -665,12 +666,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     red.reduce_tile(sv, C, dl, lane);
     ++nconsumed;
   }
+  float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
   if constexpr (QT == 16) {
     red16.drain(C, dl, lane);
-    if (lane < red16.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red16.myscore;
+    if (lane < red16.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red16.myscore;
   } else {
     red.drain(C, dl, lane);
-    if (lane < red.jdoc) p.scores[(int64_t)qi * p.ncand + c_begin + lane] = red.myscore;
+    if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
   }
 }
 

@@ -203,9 +203,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       const int qi = min(q0 + x, p.nq - 1);
       int qlen = p.Lq;
       if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
-      const bool live = n < qlen;
-      const int64_t src = ((int64_t)qi * p.Lq + (live ? n : 0)) * p.h + kb * 128 + c * EPC;
-      const float qs = (masked && live) ? load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + n) : 1.0f;
+      const int qtok = p.q_tok0 + n;  // queries longer than 32 tokens: one launch per 32
+      const bool live = qtok < qlen;
+      const int64_t src = ((int64_t)qi * p.Lq + (live ? qtok : 0)) * p.h + kb * 128 + c * EPC;
+      const float qs = (masked && live) ? load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + qtok) : 1.0f;
       float q[EPC];
 #pragma unroll
       for (int j = 0; j < EPC; ++j) {
@@ -342,7 +343,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   red.drain(C, dl, lane, argq, p.Lq);
 #pragma unroll
   for (int x = 0; x < QB; ++x)
-    if (lane < red.jdoc && q0 + x < p.nq) p.scores[(int64_t)(q0 + x) * p.ncand + c_begin + lane] = red.myscore[x];
+    if (lane < red.jdoc && q0 + x < p.nq) {
+      float* const cell = p.scores + (int64_t)(q0 + x) * p.ncand + c_begin + lane;
+      *cell = (p.accum ? *cell : 0.0f) + red.myscore[x];
+    }
 }
 
 }  // namespace maxsim

@@ -69,8 +69,9 @@ const char* maxsim_strerror(int code);
  *   q_mask  [nq, Lq], d_mask [nd, Ld]  element type `mask_dtype` (both), any numeric values
  *   out     [nq, nd] float32 (the arithmetic is fp32 whatever `dtype` is)
  * nq == 0 or nd == 0 is a no-op; Lq == 0 writes zeros; Ld == 0 -> MAXSIM_EEMPTY; h >= 0.
- * Fast paths (MFMA + LDS-DMA streaming): Lq <= 32 and h a multiple of 128 up to 1024, any of the three dtypes
- * (h == 128 fp32 keeps the query tile in registers).  Every other shape runs the generic kernel.
+ * Fast paths (MFMA + LDS-DMA streaming): h a multiple of 128 up to 1024, any of the three dtypes (h == 128 fp32
+ * keeps the query tile in registers); queries longer than 32 tokens take one launch per 32 tokens (the sum over
+ * query tokens is additive).  Every other shape runs the generic kernel.
  */
 int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
                        int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, void* stream);
@@ -113,7 +114,7 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
  *   cand_pids   [nq, ncand] int64; an entry < 0 or >= n_docs is a padding slot: its score is -inf
  *   scores      [nq, ncand] float32
  * A doc with doclens == 0 scores 0.  ncand == 0 -> MAXSIM_EEMPTY (colbert_ranker.py:76).
- * Fast paths (MFMA + LDS-DMA streaming): Lq <= 32 and h == 128 (query tile in registers; index F32: f32-input
+ * Fast paths (MFMA + LDS-DMA streaming; queries longer than 32 tokens: one launch per 32): h == 128 (query tile in registers; index F32: f32-input
  * MFMA, exact; F16/BF16: 16-bit MFMA with the fp32 query split into 2/3 pieces, no query bits dropped) or
  * h a multiple of 128 up to 1024 (query tile staged in LDS; e.g. the reference's default dim 768).
  * n_tokens must be < 2^32 for the fast paths.  Everything else runs the generic kernel.

@@ -74,7 +74,7 @@ def test_model_object_is_dropin(ca):
     torch.testing.assert_close(out, exp, rtol=0, atol=ATOL32)
 
 
-@pytest.mark.parametrize("shape", [(3, 5, 7, 9, 16), (2, 33, 40, 65, 128), (1, 1, 1, 1, 1), (2, 32, 3, 31, 128),
+@pytest.mark.parametrize("shape", [(3, 5, 7, 9, 16), (2, 33, 40, 65, 128), (1, 1, 1, 1, 1), (2, 32, 3, 31, 128), (2, 65, 5, 40, 256),
                                    (2, 32, 3, 33, 128), (5, 17, 4, 64, 128), (1, 40, 2, 10, 64)])
 @pytest.mark.parametrize("mask_dtype", [torch.int64, torch.float32, torch.bool, torch.int32])
 def test_dense_random_shapes(ca, shape, mask_dtype):
@@ -220,6 +220,9 @@ def _random_index(gen, ndocs, h, lo, hi, dtype=torch.float16):
     dict(ndocs=32, h=1024, lo=20, hi=40, nq=2, ncand=32, Lq=32, dtype=torch.float16, qdtype=torch.float16),
     dict(ndocs=20, h=640, lo=1, hi=40, nq=1, ncand=20, Lq=32, dtype=torch.float32),
     dict(ndocs=20, h=1152, lo=1, hi=40, nq=1, ncand=20, Lq=4, dtype=torch.bfloat16),        # > 1024: generic kernel
+    dict(ndocs=60, h=128, lo=1, hi=90, nq=3, ncand=50, Lq=40, dtype=torch.float32),         # Lq > 32: two query slices
+    dict(ndocs=60, h=128, lo=1, hi=90, nq=2, ncand=50, Lq=64, dtype=torch.float16),
+    dict(ndocs=16, h=768, lo=50, hi=120, nq=2, ncand=16, Lq=70, dtype=torch.bfloat16, qdtype=torch.bfloat16),
 ])
 def test_rerank_random_vs_oracle(ca, cfg):
     from oracle.maxsim_oracle import RefRanker
