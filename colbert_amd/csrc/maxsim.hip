@@ -82,10 +82,10 @@ int launch_stream(Params& p, hipStream_t st) {
 
 // Query-in-LDS streaming kernel (h = 128 * KB): QB query images of NPQ x KB x sub-tile bytes each, the rest of the
 // 160 KiB goes to the waves' rings: as many waves (<= 8) as fit with NT sub-tiles each.
-template <int MODE, int DT, int NPQ, bool AM, int QB>
+template <int MODE, int DT, int NPQ, bool AM, int QB, bool PART = false>
 int launch_stream_bigh_q(Params& p, hipStream_t st) {
   constexpr int SUB = StreamTraits<DT>::TILE;
-  const int KB = p.h / 128;
+  const int KB = (p.h + 127) / 128;
   const int qbytes = QB * NPQ * KB * SUB;
   const int avail = 160 * 1024 - qbytes;
   int dpwv = env_int("MAXSIM_DPW", 0);
@@ -100,14 +100,19 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)(nqblk * p.nchunk)), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
     return check_launch();
   };
-  if constexpr (QB == 1) {
-    if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
-    if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
-  } else {  // several queries per workgroup: the matrix work per sub-tile is QB x longer, one sub-tile ahead suffices
-    if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
+  if constexpr (PART) {  // odd widths: one configuration (keeps the number of instantiations down)
+    if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB, true>, 4, 1);
+    return MAXSIM_ERANGE;
+  } else {
+    if constexpr (QB == 1) {
+      if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
+      if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
+    } else {  // several queries per workgroup: the matrix work per sub-tile is QB x longer, one sub-tile ahead suffices
+      if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
+    }
+    if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB>, 4, 1);
+    return MAXSIM_ERANGE;
   }
-  if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB>, 4, 1);
-  return MAXSIM_ERANGE;
 }
 
 // All-pairs (dense) launches share each doc sub-tile between QB queries of a workgroup: the largest QB whose query
@@ -115,6 +120,7 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
 // (QB = 8 spills).
 template <int MODE, int DT, int NPQ, bool AM>
 int launch_stream_bigh(Params& p, hipStream_t st) {
+  if (p.h & 127) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 1, true>(p, st);  // partial last block
   if constexpr (MODE == MODE_DENSE) {
     constexpr int SUB = StreamTraits<DT>::TILE;
     const int qimg = NPQ * (p.h / 128) * SUB;
@@ -219,7 +225,8 @@ static int score_dense_impl(const void* Q, const void* D, const void* q_mask, co
   const bool stream_ok = (Lq <= 32 || (!argmax && Lq <= MAX_LQ_SLICED)) && p.n_tokens <= 0xffffffffLL;
   if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128)
     return for_query_slices(p, [&] { return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st); });
-  if (stream_ok && h >= 128 && h <= 1024 && (h & 127) == 0) {
+  const int esz = dtype == MAXSIM_F32 ? 4 : 2;
+  if (stream_ok && h >= 16 && h <= 1024 && ((h * esz) & 15) == 0) {
     int rc = argmax ? launch_bigh<MODE_DENSE, true>(p, dtype, st)
                     : for_query_slices(p, [&] { return launch_bigh<MODE_DENSE, false>(p, dtype, st); });
     if (rc != MAXSIM_ERANGE) return rc;
@@ -321,7 +328,8 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
       return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
     });
   }
-  if (h > 128 && h <= 1024 && (h & 127) == 0 && stream_ok) {
+  const int esz = (index_dtype == MAXSIM_F32 || index_dtype == MAXSIM_F32_FAST) ? 4 : 2;
+  if (h >= 16 && h <= 1024 && ((h * esz) & 15) == 0 && stream_ok) {
     const int dt = index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype;
     int rc = for_query_slices(p, [&] { return launch_bigh<MODE_RERANK, false>(p, dt, st); });
     if (rc != MAXSIM_ERANGE) return rc;

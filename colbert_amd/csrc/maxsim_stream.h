@@ -158,7 +158,9 @@ __device__ __forceinline__ TileMap fill_tile(Cursor& F, const DocLanes& dl, int 
 // Issues the NDMA LDS-DMA instructions of one tile (or of one 128-dim block of it): instruction i moves the RPD row
 // slots RPD*i + lane/LPR, 1 KiB in all, to l + 1024 i.  `rowbytes` = bytes per token row, `blk` = byte offset of the
 // block inside the row.  Chunk position p of slot m receives source chunk p ^ (m & 15).
-template <int NDMA, int RPD, int LPR>
+// PART: the row's last 128-dim block may be partial (h not a multiple of 128): chunks past the row end are redirected
+// to the row's first chunk (valid, finite data; the query image is zero there, so they contribute exactly 0).
+template <int NDMA, int RPD, int LPR, bool PART = false>
 __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, uint32_t blk, char* l,
                                            const TileMap& t, int lane) {
   // (the lane constants are made opaque so that hipcc recomputes the 2-3 VALU ops per instruction instead of keeping
@@ -166,11 +168,13 @@ __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, u
   int ds0 = lane / LPR, dch = lane % LPR;
   asm volatile("" : "+v"(ds0), "+v"(dch));
   if (t.kind == 1) {  // one contiguous burst: uniform base in SGPRs + per-lane 32-bit offset
-    const char* base = tok + (uint64_t)t.base0 * rowbytes + blk;
+    const char* base = tok + (uint64_t)t.base0 * rowbytes + (PART ? 0u : blk);
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const int slot = RPD * i + ds0;
-      const uint32_t off = (uint32_t)slot * rowbytes + 16u * (uint32_t)(dch ^ (slot & 15));
+      uint32_t inrow = 16u * (uint32_t)(dch ^ (slot & 15));
+      if (PART) inrow = (blk + inrow < rowbytes) ? blk + inrow : 0u;  // past the row end -> byte 0 of the row
+      const uint32_t off = (uint32_t)slot * rowbytes + inrow;
       __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
     }
   } else if (t.kind == 2) {  // the end of one doc and the start of the next: two uniform bases, selected per lane
@@ -178,7 +182,9 @@ __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, u
     for (int i = 0; i < NDMA; ++i) {
       const int slot = RPD * i + ds0;
       const uint32_t row = (slot < t.split ? t.base0 : t.base1) + (uint32_t)slot;
-      const char* g = tok + (uint64_t)row * rowbytes + blk + 16u * (uint32_t)(dch ^ (slot & 15));
+      uint32_t inrow = blk + 16u * (uint32_t)(dch ^ (slot & 15));
+      if (PART && inrow >= rowbytes) inrow = 0u;
+      const char* g = tok + (uint64_t)row * rowbytes + inrow;
       __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
     }
   } else {  // many short docs (or the stream's padded last tile): each slot's row comes from the lane that owns it
@@ -188,7 +194,9 @@ __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, u
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
       const int slot = RPD * i + ds0;
-      const char* g = tok + (uint64_t)rows[i] * rowbytes + blk + 16u * (uint32_t)(dch ^ (slot & 15));
+      uint32_t inrow = blk + 16u * (uint32_t)(dch ^ (slot & 15));
+      if (PART && inrow >= rowbytes) inrow = 0u;
+      const char* g = tok + (uint64_t)rows[i] * rowbytes + inrow;
       __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
     }
   }

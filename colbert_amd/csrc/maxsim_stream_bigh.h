@@ -130,7 +130,9 @@ struct MultiReducer {
   }
 };
 
-template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB>
+// PART: h is not a multiple of 128 (but of 16 bytes): the last block is partial -- the query image is zero past h and
+// the doc fetch never leaves the row (issue_rows<PART>).
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
   static_assert(!AM || MODE == MODE_DENSE, "arg-max tracking is a dense (training-form) feature");
@@ -142,7 +144,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   constexpr int SUB = T::TILE;   // bytes of a sub-tile (32 rows x one block) == one query piece block
   constexpr int NDMA = T::NDMA, RPD = T::RPD, LPR = T::LPR, NRD = T::NRD;
   constexpr int ESZ = BLKB / 128;
-  const int KB = p.h >> 7;
+  const int KB = (p.h + 127) >> 7;
   const uint32_t rowbytes = (uint32_t)p.h * ESZ;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
@@ -174,7 +176,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   auto fetch_next = [&](int buf) __attribute__((always_inline)) -> bool {
     if (fkb == 0) ft = fill_tile(F, dl, r);
     if (ft.kind == 0) return false;
-    issue_rows<NDMA, RPD, LPR>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
+    issue_rows<NDMA, RPD, LPR, PART>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
     fkb = (fkb + 1 == KB) ? 0 : fkb + 1;
     return true;
   };
@@ -210,7 +212,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       float q[EPC];
 #pragma unroll
       for (int j = 0; j < EPC; ++j) {
-        q[j] = live ? load_q(p.Q, p.q_dtype, src + j) : 0.0f;
+        const bool indim = !PART || (kb * 128 + c * EPC + j < p.h);
+        q[j] = (live && indim) ? load_q(p.Q, p.q_dtype, src + (indim ? j : 0)) : 0.0f;
         if (MODE == MODE_DENSE) q[j] *= qs;  // Q * q_mask[..., None], BaseModel.py:42
       }
       char* dst = qlds + x * qimg + kb * SUB + n * BLKB + 16 * (c ^ (n & 15));

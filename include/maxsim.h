@@ -69,7 +69,7 @@ const char* maxsim_strerror(int code);
  *   q_mask  [nq, Lq], d_mask [nd, Ld]  element type `mask_dtype` (both), any numeric values
  *   out     [nq, nd] float32 (the arithmetic is fp32 whatever `dtype` is)
  * nq == 0 or nd == 0 is a no-op; Lq == 0 writes zeros; Ld == 0 -> MAXSIM_EEMPTY; h >= 0.
- * Fast paths (MFMA + LDS-DMA streaming): h a multiple of 128 up to 1024, any of the three dtypes (h == 128 fp32
+ * Fast paths (MFMA + LDS-DMA streaming): 16 <= h <= 1024 with 16-byte-aligned rows, any of the three dtypes (h == 128 fp32
  * keeps the query tile in registers); queries longer than 32 tokens take one launch per 32 tokens (the sum over
  * query tokens is additive).  Every other shape runs the generic kernel.
  */
@@ -116,7 +116,8 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
  * A doc with doclens == 0 scores 0.  ncand == 0 -> MAXSIM_EEMPTY (colbert_ranker.py:76).
  * Fast paths (MFMA + LDS-DMA streaming; queries longer than 32 tokens: one launch per 32): h == 128 (query tile in registers; index F32: f32-input
  * MFMA, exact; F16/BF16: 16-bit MFMA with the fp32 query split into 2/3 pieces, no query bits dropped) or
- * h a multiple of 128 up to 1024 (query tile staged in LDS; e.g. the reference's default dim 768).
+ * any 16 <= h <= 1024 whose rows are a multiple of 16 bytes (query tile staged in LDS; e.g. the reference's default
+ * dim 768; widths that are not a multiple of 128 pad the last 128-dim block with zeros on the query side).
  * n_tokens must be < 2^32 for the fast paths.  Everything else runs the generic kernel.
  */
 int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,

@@ -220,6 +220,10 @@ def _random_index(gen, ndocs, h, lo, hi, dtype=torch.float16):
     dict(ndocs=32, h=1024, lo=20, hi=40, nq=2, ncand=32, Lq=32, dtype=torch.float16, qdtype=torch.float16),
     dict(ndocs=20, h=640, lo=1, hi=40, nq=1, ncand=20, Lq=32, dtype=torch.float32),
     dict(ndocs=20, h=1152, lo=1, hi=40, nq=1, ncand=20, Lq=4, dtype=torch.bfloat16),        # > 1024: generic kernel
+    dict(ndocs=50, h=64, lo=1, hi=90, nq=3, ncand=40, Lq=32, dtype=torch.float16),          # partial 128-dim block
+    dict(ndocs=50, h=96, lo=1, hi=90, nq=2, ncand=40, Lq=20, dtype=torch.float32),
+    dict(ndocs=50, h=200, lo=30, hi=70, nq=2, ncand=40, Lq=32, dtype=torch.bfloat16, qdtype=torch.bfloat16),
+    dict(ndocs=50, h=20, lo=1, hi=40, nq=2, ncand=40, Lq=5, dtype=torch.float32),
     dict(ndocs=60, h=128, lo=1, hi=90, nq=3, ncand=50, Lq=40, dtype=torch.float32),         # Lq > 32: two query slices
     dict(ndocs=60, h=128, lo=1, hi=90, nq=2, ncand=50, Lq=64, dtype=torch.float16),
     dict(ndocs=16, h=768, lo=50, hi=120, nq=2, ncand=16, Lq=70, dtype=torch.bfloat16, qdtype=torch.bfloat16),
@@ -527,8 +531,8 @@ def test_randomized_rerank_sweep(ca, case):
     cand[1, 0] = ndocs + 5
     q_len = torch.randint(1, Lq + 1, (nq,), generator=gen).int() if use_qlen else None
     sc = r.score_candidates(Q, cand, q_len=q_len).cpu()
-    loose = dtype == torch.bfloat16 and h not in (128,) and h % 128 == 0 and h <= 1024
-    generic16 = dtype != torch.float32 and (h % 128 != 0 or h > 1024)
+    loose = dtype == torch.bfloat16 and h != 128 and h % 8 == 0 and h <= 1024
+    generic16 = dtype != torch.float32 and (h % 8 != 0 or h > 1024)
     atol = ATOL16 if (loose or generic16) else (1e-5 * 10 if kw else ATOL32)
     for qi in range(nq):
         ql = int(q_len[qi]) if use_qlen else Lq
