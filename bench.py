@@ -109,7 +109,7 @@ def main():
     ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
-    ap.add_argument("--fp32-mode", default="exact", choices=["exact", "fast"],
+    ap.add_argument("--fp32-mode", default="exact", choices=["exact", "fast", "bf16x3"],
                     help="fp32 index only: exact f32 MFMA (default) or the split-fp16 fast mode")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the host-side legs (cpu_baseline and the single-query latency probe): profiling runs")

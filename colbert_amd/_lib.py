@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MAXSIM_LIB", os.path.join(_HERE, "libmaxsim.so"))  # MAXSIM_LIB: A/B builds
 
 # include/maxsim.h
-F32, F16, BF16, F32_FAST = 0, 1, 2, 3
+F32, F16, BF16, F32_FAST, F32_BF16X3 = 0, 1, 2, 3, 4
 MASK_NONE, MASK_I64, MASK_I32, MASK_F32, MASK_U8 = 0, 1, 2, 3, 4
 OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 

@@ -297,7 +297,7 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
                   const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
                   float* scores, void* stream) {
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
-  if (index_dtype < MAXSIM_F32 || index_dtype > MAXSIM_F32_FAST) return MAXSIM_EINVAL;
+  if (index_dtype < MAXSIM_F32 || index_dtype > MAXSIM_F32_BF16X3) return MAXSIM_EINVAL;
   if (q_dtype < MAXSIM_F32 || q_dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
   if (ncand == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
   if (nq == 0) return MAXSIM_OK;
@@ -324,17 +324,18 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
     return for_query_slices(p, [&] {
       if (index_dtype == MAXSIM_F32) return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
       if (index_dtype == MAXSIM_F32_FAST) return launch_stream<MODE_RERANK, MAXSIM_F32_FAST>(p, st);
+      if (index_dtype == MAXSIM_F32_BF16X3) return launch_stream<MODE_RERANK, MAXSIM_F32_BF16X3>(p, st);
       if (index_dtype == MAXSIM_F16) return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
       return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
     });
   }
-  const int esz = (index_dtype == MAXSIM_F32 || index_dtype == MAXSIM_F32_FAST) ? 4 : 2;
+  const int esz = (index_dtype == MAXSIM_F32 || index_dtype >= MAXSIM_F32_FAST) ? 4 : 2;
   if (h >= 16 && h <= 1024 && ((h * esz) & 15) == 0 && stream_ok) {
-    const int dt = index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype;
+    const int dt = index_dtype >= MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype;
     int rc = for_query_slices(p, [&] { return launch_bigh<MODE_RERANK, false>(p, dt, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }
-  return launch_generic<MODE_RERANK>(p, index_dtype == MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
+  return launch_generic<MODE_RERANK>(p, index_dtype >= MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
 }
 
 int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,

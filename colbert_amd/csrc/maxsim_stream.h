@@ -38,6 +38,16 @@ template <>
 struct StreamTraits<F32S> {
   static constexpr int ROWB = 512, TILE = 16384, NDMA = 16, RPD = 2, LPR = 32, NRD = 16, NP = 2;
 };
+// fp32 storage, "3 x bf16" contraction: every fp32 value is cut EXACTLY into three bf16 pieces by truncation
+// (x = t0 + t1 + t2, 8 + 8 + 8 significant bits; bf16 has the fp32 exponent range, so no magnitude restriction), and the
+// six piece products of order <= 2 (t0q0, t0q1, t1q0, t0q2, t1q1, t2q0) run on the bf16 matrix pipe with fp32
+// accumulation.  Piece products are exact in fp32; the dropped terms are <= 3 * 2^-24 relative -- fp32-class accuracy
+// (like any fp32 GEMM it differs from a sequential fmaf chain only in rounding/summation order), 2.7x less matrix time.
+constexpr int F32X = MAXSIM_F32_BF16X3;
+template <>
+struct StreamTraits<F32X> {
+  static constexpr int ROWB = 512, TILE = 16384, NDMA = 16, RPD = 2, LPR = 32, NRD = 16, NP = 3;
+};
 template <>
 struct StreamTraits<MAXSIM_F16> {
   static constexpr int ROWB = 256, TILE = 8192, NDMA = 8, RPD = 4, LPR = 16, NRD = 8, NP = 2;
@@ -520,7 +530,15 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float x = live ? q[j] : 0.0f;
-          if constexpr (F16Q) {
+          if constexpr (DT == F32X) {  // exact truncation split: x = t0 + t1 + t2
+            const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
+            const float r1 = x - __uint_as_float(u0);
+            const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
+            const float r2 = r1 - __uint_as_float(u1);
+            pc[0][j] = (uint16_t)(u0 >> 16);
+            pc[1][j] = (uint16_t)(u1 >> 16);
+            pc[NP - 1][j] = (uint16_t)(__float_as_uint(r2) >> 16);
+          } else if constexpr (F16Q) {
             _Float16 hi = (_Float16)x;
             _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
             __builtin_memcpy(&pc[0][j], &hi, 2);
@@ -562,7 +580,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
         a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i >> 3) + n16) * ROWB + 16 * ((4 * (i & 7) + (lane >> 4)) ^ n16));
       } else {
         // chunk of the row this lane needs for operand i: 16-bit MFMA k-step = 8 consecutive dims per lane half
-        const int c = (DT == F32S) ? (4 * (i >> 1) + 2 * hh + (i & 1)) : (2 * i + hh);
+        const int c = (DT == F32S || DT == F32X) ? (4 * (i >> 1) + 2 * hh + (i & 1)) : (2 * i + hh);
         a[i] = *(const u32x4*)(tl + 16 * (c ^ rsw));
       }
     }
@@ -623,6 +641,40 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
 #pragma unroll
       for (int v = 0; v < 16; ++v) sv[v] = acc[v];
+    } else if constexpr (DT == F32X) {
+      f32x16 acc0 = (f32x16)(0.0f);  // one accumulator (register budget): small piece products first within a k-step
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const u32x4 x0 = a[2 * i], x1 = a[2 * i + 1];
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(x0), "v"(x1));
+          continue;
+        }
+        u32x4 t0, t1, t2;  // packed bf16 pairs: element j = dims 2j, 2j+1 of this lane's 8
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+          const uint32_t xa = w < 2 ? x0[2 * w] : x1[2 * w - 4], xb = w < 2 ? x0[2 * w + 1] : x1[2 * w - 3];
+          const float ra = __uint_as_float(xa) - __uint_as_float(xa & 0xffff0000u);
+          const float rb = __uint_as_float(xb) - __uint_as_float(xb & 0xffff0000u);
+          const uint32_t ua = __float_as_uint(ra), ub = __float_as_uint(rb);
+          const float sa = ra - __uint_as_float(ua & 0xffff0000u);
+          const float sb = rb - __uint_as_float(ub & 0xffff0000u);
+          t0[w] = __builtin_amdgcn_perm(xb, xa, 0x07060302u);  // (hi16(xb) << 16) | hi16(xa)
+          t1[w] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+          t2[w] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+        }
+        const bf16x8 d0 = __builtin_bit_cast(bf16x8, t0), d1 = __builtin_bit_cast(bf16x8, t1), d2 = __builtin_bit_cast(bf16x8, t2);
+        const bf16x8 q0 = __builtin_bit_cast(bf16x8, qp[0][i]), q1 = __builtin_bit_cast(bf16x8, qp[1][i]),
+                     q2 = __builtin_bit_cast(bf16x8, qp[NP - 1][i]);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d2, q0, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, q1, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, q2, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d1, q0, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, q1, acc0, 0, 0, 0);
+        acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(d0, q0, acc0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int v = 0; v < 16; ++v) sv[v] = acc0[v];
     } else if constexpr (DT == F32S) {
       f32x16 acc0 = (f32x16)(0.0f), acc1 = (f32x16)(0.0f);
 #pragma unroll

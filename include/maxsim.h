@@ -40,6 +40,9 @@ extern "C" {
 /* maxsim_rerank index_dtype only: fp32 storage, contraction on the 16-bit matrix pipe with BOTH operands split
    into fp16 pieces on the fly (|error| ~1e-6 on a score; needs |x| < 65504, e.g. L2-normalised embeddings) */
 #define MAXSIM_F32_FAST 3
+/* maxsim_rerank index_dtype only: fp32 storage, "3 x bf16" contraction: both operands cut exactly into three bf16
+   pieces, six piece products on the bf16 matrix pipe, fp32 accumulation: fp32-class accuracy, no magnitude limit */
+#define MAXSIM_F32_BF16X3 4
 
 /* element types of the mask tensors of maxsim_score_dense */
 #define MAXSIM_MASK_NONE 0 /* both mask pointers ignored: all ones */

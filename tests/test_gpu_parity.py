@@ -408,6 +408,31 @@ def test_retrieve_then_rerank_end_to_end(ca):
         assert tp[qi].tolist() == ep
 
 
+def test_fp32_bf16x3_mode_is_fp32_accurate(ca):
+    """fp32 index, "3 x bf16" contraction (exact bf16 splits, six piece products on the bf16 matrix pipe): its error
+    against a float64 evaluation is of the same size as the exact f32 MFMA path's -- fp32-class accuracy -- also for
+    un-normalised, large-magnitude embeddings (no magnitude restriction, unlike the fp16-split fast mode)."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(22)
+    for scale in (1.0, 3.0e4):
+        doclens = torch.randint(1, 181, (200,), generator=gen).tolist()
+        emb = nrm(gen, sum(doclens), 128) * scale
+        Q = nrm(gen, 3, 32, 128) * scale
+        cand = torch.stack([torch.randperm(200, generator=gen)[:90] for _ in range(3)])
+        rs = {m: ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=128, index_dtype=torch.float32, fp32_mode=m)
+              for m in ("exact", "bf16x3")}
+        offs = rs["exact"].doclens_pfxsum
+        nopad = torch.zeros(200, dtype=torch.long)
+        err = {}
+        for m, r in rs.items():
+            r.d_pad_len.zero_()                                    # no 0-floor: pure sum-of-max
+            sc = r.score_candidates(Q, cand).cpu().double().numpy()
+            ref = np.stack([ragged_scores_f64(emb, doclens, offs, nopad, Q[qi], cand[qi].tolist()) for qi in range(3)])
+            err[m] = np.abs(sc - ref).max() / (scale * scale)
+        assert err["exact"] <= 2e-5 and err["bf16x3"] <= 2e-5, err
+        assert err["bf16x3"] <= 4 * err["exact"] + 1e-6, err
+
+
 def test_fp32_fast_mode(ca, golden):
     """fp32 index, opt-in "fast" contraction (both operands split into fp16 pieces, 16-bit MFMA): same scores to 1e-5."""
     from oracle.maxsim_oracle import RefRanker
