@@ -53,11 +53,21 @@ class ShardedRanker:
         self.score_fn = score_fn if score_fn is not None else local_ranker.score_candidates
         self.topk_fn = topk_fn if topk_fn is not None else local_ranker.topk
 
-    def local_topk(self, Q, cand_global, depth, q_len=None):
+    def local_topk(self, Q, cand_global, depth, q_len=None, compact=True):
         cand_local, inr = localize(cand_global, self.lo, self.hi)
-        scores = self.score_fn(Q, cand_local, q_len) if q_len is not None else self.score_fn(Q, cand_local)
+        gp = torch.where(inr, cand_global, torch.full_like(cand_global, -1))
         k = min(int(depth), cand_global.size(1))
-        gp = torch.where(inr.to(scores.device), cand_global.to(scores.device), torch.full_like(cand_local, -1).to(scores.device))
+        if compact and cand_global.size(1) > k:
+            # a shard owns ~1/world of each list: move its candidates to the front and cut the width to the longest
+            # local list (never below k, so the [nq, k] gather shape is the same on every rank) -- otherwise most
+            # descriptor lanes of the rerank kernel would hold padding slots
+            order = torch.argsort((~inr).to(torch.int8), dim=1, stable=True)
+            width = max(int(inr.sum(1).max().item()), k)
+            order = order[:, :width]
+            cand_local = torch.gather(cand_local, 1, order)
+            gp = torch.gather(gp, 1, order)
+        scores = self.score_fn(Q, cand_local, q_len) if q_len is not None else self.score_fn(Q, cand_local)
+        gp = gp.to(scores.device)
         return self.topk_fn(scores, gp, k)          # (pids [nq,k] global, scores [nq,k]); padding slots = (-1, -inf)
 
     def rerank_batch(self, Q, cand_global, depth=10, q_len=None):

@@ -601,3 +601,26 @@ def test_side_stream_and_hipgraph_replay(ca):
     torch.cuda.synchronize()
     e2p, e2s = r.rerank_batch(Q2, cand2, depth=10)
     assert torch.equal(gp, e2p) and torch.equal(gs, e2s)
+
+
+def test_sharded_ranker_local_leg_on_gpu(ca):
+    """One shard of a doc-sharded index on the GPU (the collective leg is covered by the gloo test): candidates outside
+    the shard's pid range are padding, the shard's own are compacted to the front, top-k carries GLOBAL pids."""
+    from colbert_amd.sharded import ShardedRanker
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(31)
+    parts, pdl = _random_index(gen, 100, 128, 5, 60, torch.float16)
+    ref = RefRanker(parts, pdl, dim=128)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=128)
+    lo, hi = 1000, 1100                                   # this shard holds global pids [1000, 1100)
+    sh = ShardedRanker(r, lo, hi)
+    Q = nrm(gen, 3, 32, 128)
+    cand = torch.stack([torch.randperm(400, generator=gen)[:64] + 900 for _ in range(3)]).cuda()   # global pids 900..1299
+    tp, ts = sh.rerank_batch(Q, cand, depth=8)
+    for qi in range(3):
+        mine = [p for p in cand[qi].tolist() if lo <= p < hi]
+        ep, es = ref.rank_forward(Q[qi:qi + 1].permute(0, 2, 1), [p - lo for p in mine], depth=8)
+        n = len(ep)
+        assert tp[qi, :n].tolist() == [p + lo for p in ep]
+        np.testing.assert_allclose(ts[qi, :n].cpu().numpy(), np.array(es), rtol=0, atol=ATOL32)
+        assert bool((tp[qi, n:] == -1).all()) and bool((ts[qi, n:] == float("-inf")).all())
