@@ -106,6 +106,8 @@ class ColbertRanker:
         """Q [nq, Lq, h] (token-major), cand_pids [nq, ncand] int64 LOCAL pids (<0 = padding slot)
         -> scores [nq, ncand] fp32 on the device."""
         dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("colbert_amd scores on the GPU only: the index must live in HBM (libmaxsim has no CPU path)")
         # a 16-bit query is passed through in its own dtype (no query bits are invented); anything else as fp32
         qdt = Q.dtype if Q.dtype in (torch.float16, torch.bfloat16) else torch.float32
         Q = Q.to(device=dev, dtype=qdt).contiguous()
