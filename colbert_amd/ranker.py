@@ -41,11 +41,15 @@ class ColbertRanker:
 
     def __init__(self, index_path=None, model=None, dim=None, *, parts=None, parts_doclens=None, device="cuda",
                  index_dtype=torch.float16, fp32_mode="exact"):
+        part_iter = None
         if index_path is not None:
             _, parts_paths, _ = index_io.get_parts(index_path)                # :18
             parts_doclens = index_io.load_doclens(index_path, flatten=False)  # :22
-            parts = [index_io.load_index_part(f) for f in parts_paths]        # :61-73
-        if parts is None or parts_doclens is None:
+            # parts are streamed to HBM one file at a time (:61-73 keeps the whole index in host RAM; here it never is)
+            part_iter = (index_io.load_index_part(f) for f in parts_paths)
+        elif parts is not None:
+            part_iter = iter(parts)
+        if part_iter is None or parts_doclens is None:
             raise ValueError("give index_path or parts+parts_doclens")
         self.maxsim_dtype = torch.float32                                     # :20
         self.parts_doclens = parts_doclens
@@ -55,15 +59,20 @@ class ColbertRanker:
         self.fp32_mode = fp32_mode
         doclens = [int(x) for y in parts_doclens for x in y]                  # flatten, utils.py:133
         self.num_embeddings = sum(doclens)
-        dim = parts[0].size(-1) if dim is None else dim
         assert index_dtype in _DT
         # one HBM-resident [num_embeddings, dim] token matrix (no +512 tail: the kernel never reads past a doc)
-        self.tensor = torch.empty(max(self.num_embeddings, 1), dim, dtype=index_dtype, device=self.device)
+        self.tensor = None
         offset = 0
-        for part, dl in zip(parts, parts_doclens):
+        for part, dl in zip(part_iter, parts_doclens):
+            if self.tensor is None:
+                dim = part.size(-1) if dim is None else dim
+                self.tensor = torch.empty(max(self.num_embeddings, 1), dim, dtype=index_dtype, device=self.device)
             endpos = offset + sum(dl)
+            assert part.size(0) == endpos - offset, (part.size(0), endpos - offset)
             self.tensor[offset:endpos] = part.to(device=self.device, dtype=index_dtype)
             offset = endpos
+            del part
+        assert self.tensor is not None and offset == self.num_embeddings
         self.init_ranker(doclens)
 
     @classmethod
