@@ -126,13 +126,17 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
-    dev = torch.device("cuda", local_rank)
+    # MAXSIM_BENCH_ONE_GPU=1: rehearsal of the N > 1 path with every rank on cuda:0 (a one-GPU box)
+    dev = torch.device("cuda", 0 if os.environ.get("MAXSIM_BENCH_ONE_GPU") else local_rank)
     torch.cuda.set_device(dev)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if os.environ.get("MAXSIM_BENCH_ONE_GPU"):
+            dist.init_process_group("gloo", rank=rank, world_size=world)     # rehearsal only (see above)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import colbert_amd
     from colbert_amd.sharded import ShardedRanker
