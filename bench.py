@@ -33,7 +33,7 @@ WORKLOADS = {
     "c2": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=False, dtype="fp32"),
     "ragged": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=True, dtype="fp32"),
     "c4": dict(lq=8, ld=8, h=128, ndocs=4_000_000, ragged=False, dtype="fp32"),
-    "c5": dict(lq=32, ld=256, h=768, ndocs=200_000, ragged=False, dtype="bf16"),
+    "c5": dict(lq=32, ld=256, h=768, ndocs=200_000, ragged=False, dtype="bf16", qdtype="bf16"),
 }
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
+    ap.add_argument("--q-dtype", default="", choices=["", "fp32", "fp16", "bf16"],
+                    help="element type the queries are handed over in (default: fp32; c5: bf16)")
     ap.add_argument("--fp32-mode", default="exact", choices=["exact", "fast", "bf16x3"],
                     help="fp32 index only: exact f32 MFMA (default) or the split-fp16 fast mode")
     ap.add_argument("--no-cpu-baseline", action="store_true",
@@ -165,6 +167,8 @@ def main():
     total = args.warmup + args.steps
     gq = torch.Generator(device=dev).manual_seed(1)            # same queries on every rank
     Q = F.normalize(torch.randn(nq, LQ, H, generator=gq, device=dev), dim=-1)
+    q_dtype = args.q_dtype or wl.get("qdtype", "fp32")
+    Q = Q.to({"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[q_dtype])
     gc = torch.Generator(device=dev).manual_seed(2 + rank)     # this shard's candidates, fresh per step
     cands = torch.randint(lo, hi, (total, nq, per), generator=gc, device=dev, dtype=torch.int64)
 
@@ -205,7 +209,7 @@ def main():
     # algorithmic bytes of ONE rerank launch on this rank: doc tokens read once + Q + pid/offset/len + score
     docs = nq * per
     cand_tokens = int(ranker.d_doclens[(cands[args.warmup:] - lo).reshape(-1)].sum().item()) / args.steps
-    alg_bytes = int(cand_tokens * H * esize + nq * LQ * H * 4 + docs * (8 + 12 + 4))
+    alg_bytes = int(cand_tokens * H * esize + nq * LQ * H * Q.element_size() + docs * (8 + 12 + 4))
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
 
     # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
@@ -231,7 +235,7 @@ def main():
                                    f"{'~120 (8..180 ragged)' if wl['ragged'] else LD} tokens, dim {H}, "
                                    f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}",
                        "queries_per_step": nq, "candidates_per_query": NCAND, "docs_per_gpu": ndocs,
-                       "index_dtype": args.index_dtype, "fp32_mode": args.fp32_mode, "parallelism": f"doc-shard x{world}"},
+                       "index_dtype": args.index_dtype, "q_dtype": q_dtype, "fp32_mode": args.fp32_mode, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),
