@@ -15,7 +15,8 @@ MASK_NONE, MASK_I64, MASK_I32, MASK_F32, MASK_U8 = 0, 1, 2, 3, 4
 OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 
 SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk",
-           "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd")
+           "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
+           "maxsim_score_dense_bwd_workspace")
 
 
 class MaxSimError(RuntimeError):
@@ -47,7 +48,9 @@ def _load():
     lib.maxsim_score_dense_fwd.restype = i32
     lib.maxsim_score_dense_fwd.argtypes = [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.maxsim_score_dense_bwd.restype = i32
-    lib.maxsim_score_dense_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.maxsim_score_dense_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]
+    lib.maxsim_score_dense_bwd_workspace.restype = i64
+    lib.maxsim_score_dense_bwd_workspace.argtypes = [i32, i32, i32, i32]
     lib.maxsim_embedding_ids_to_pids.restype = i32
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
     return lib

@@ -246,9 +246,15 @@ int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, con
   return score_dense_impl(Q, D, q_mask, d_mask, nq, nd, Lq, Ld, h, dtype, mask_dtype, out, argmax, stream);
 }
 
+int64_t maxsim_score_dense_bwd_workspace(int nq, int nd, int Lq, int Ld) {
+  if (nq < 0 || nd < 0 || Lq < 0 || Ld < 0) return 0;
+  return ((int64_t)nd * ((int64_t)nq * Lq) + (int64_t)nd * (Ld + 1)) * (int64_t)sizeof(int32_t);
+}
+
 int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, const void* d_mask,
                            const int32_t* argmax, const float* grad_out, int nq, int nd, int Lq, int Ld, int h,
-                           int dtype, int mask_dtype, float* dQ, float* dD, void* stream) {
+                           int dtype, int mask_dtype, float* dQ, float* dD, void* workspace, int64_t workspace_bytes,
+                           void* stream) {
   if (nq < 0 || nd < 0 || Lq < 0 || Ld < 0 || h < 0) return MAXSIM_EINVAL;
   if (dtype < MAXSIM_F32 || dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
   if (mask_dtype < MAXSIM_MASK_NONE || mask_dtype > MAXSIM_MASK_U8) return MAXSIM_EINVAL;
@@ -257,8 +263,13 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   const int64_t nQ = (int64_t)nq * Lq * h, nD = (int64_t)nd * Ld * h;
   const bool degenerate = nq == 0 || nd == 0 || Lq == 0 || Ld == 0 || h == 0;
   const bool dd_lds = Ld * 256 <= 150 * 1024;  // the doc's [Ld][64] fp32 slab fits in LDS
+  // preferred: per-doc inverse index in the caller's workspace (then dD is fully overwritten row by row)
+  const int64_t idx_lds = (2 * ((int64_t)Ld + 1) + (int64_t)nq * Lq) * 4;  // histogram + starts + the doc's item list
+  const bool vec8 = (h & 7) == 0;                                            // 16-byte row chunks
+  const bool dd_idx = vec8 && workspace && workspace_bytes >= maxsim_score_dense_bwd_workspace(nq, nd, Lq, Ld) &&
+                      idx_lds <= 150 * 1024 && ((int64_t)nd * Ld + 3) / 4 <= 0x7fffffffLL;
   if (dQ && nQ > 0 && degenerate && hipMemsetAsync(dQ, 0, nQ * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
-  if (dD && nD > 0 && (degenerate || !dd_lds) && hipMemsetAsync(dD, 0, nD * sizeof(float), st) != hipSuccess)
+  if (dD && nD > 0 && (degenerate || (!dd_lds && !dd_idx)) && hipMemsetAsync(dD, 0, nD * sizeof(float), st) != hipSuccess)
     return MAXSIM_ELAUNCH;
   if (degenerate) return MAXSIM_OK;
   if (!Q || !D || !argmax || !grad_out) return MAXSIM_EINVAL;
@@ -269,10 +280,24 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   int rc = MAXSIM_OK;
 #define BWD_LAUNCH(DT)                                                                                              \
   do {                                                                                                              \
-    if (dQ)                                                                                                         \
+    if (dQ && vec8)                                                                                                 \
+      hipLaunchKernelGGL((k_maxsim_bwd_dq_v8<DT>), dim3((unsigned)(nq * Lq)), dim3(128), 0, st, D, q_mask, d_mask,  \
+                         mask_dtype, argmax, grad_out, dQ, nd, Lq, Ld, h);                                          \
+    else if (dQ)                                                                                                    \
       hipLaunchKernelGGL((k_maxsim_bwd_dq<DT>), dim3((unsigned)(nq * Lq)), dim3(256), 0, st, D, q_mask, d_mask,     \
                          mask_dtype, argmax, grad_out, dQ, nd, Lq, Ld, h);                                          \
-    if (dD && dd_lds) {                                                                                             \
+    if (dD && dd_idx) {                                                                                             \
+      int32_t* ws_start = (int32_t*)workspace;                                                                      \
+      int32_t* ws_items = ws_start + (int64_t)nd * (Ld + 1);                                                        \
+      const int lb = (int)idx_lds;                                                                                  \
+      rc = allow_lds(k_maxsim_bwd_index, lb);                                                                       \
+      if (rc == MAXSIM_OK) {                                                                                        \
+        hipLaunchKernelGGL(k_maxsim_bwd_index, dim3((unsigned)nd), dim3(1024), lb, st, q_mask, d_mask, mask_dtype,  \
+                           argmax, grad_out, ws_start, ws_items, nq, nd, Lq, Ld);                                   \
+        hipLaunchKernelGGL((k_maxsim_bwd_dd_rows<DT>), dim3((unsigned)(((int64_t)nd * Ld + 3) / 4)), dim3(256), 0,  \
+                           st, Q, q_mask, d_mask, mask_dtype, grad_out, ws_start, ws_items, dD, nq, nd, Lq, Ld, h); \
+      }                                                                                                             \
+    } else if (dD && dd_lds) {                                                                                      \
       rc = allow_lds(k_maxsim_bwd_dd_lds<DT>, Ld * 256);                                                            \
       if (rc == MAXSIM_OK)                                                                                          \
         hipLaunchKernelGGL((k_maxsim_bwd_dd_lds<DT>), dim3((unsigned)(nd * nchunk)), dim3(1024), Ld * 256, st, Q,   \

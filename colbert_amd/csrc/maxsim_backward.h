@@ -12,6 +12,24 @@
 
 namespace maxsim {
 
+// 8 consecutive elements starting at element index i (i % 8 == 0, 16-byte aligned rows) as floats
+template <int DT>
+__device__ __forceinline__ void load8(const void* p, int64_t i, float (&x)[8]) {
+  if constexpr (DT == MAXSIM_F32) {
+    const f32x4 a = *(const f32x4*)((const float*)p + i), b = *(const f32x4*)((const float*)p + i + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { x[j] = a[j]; x[4 + j] = b[j]; }
+  } else {
+    const u32x4 w = *(const u32x4*)((const uint16_t*)p + i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint16_t lo = (uint16_t)(w[j] & 0xffffu), hi = (uint16_t)(w[j] >> 16);
+      x[2 * j] = DT == MAXSIM_F16 ? f16_to_f32(lo) : bf16_to_f32(lo);
+      x[2 * j + 1] = DT == MAXSIM_F16 ? f16_to_f32(hi) : bf16_to_f32(hi);
+    }
+  }
+}
+
 __device__ __forceinline__ float lane_f32(float v, int l) {
   return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), l));
 }
@@ -72,6 +90,57 @@ __global__ void __launch_bounds__(256) k_maxsim_bwd_dq(const void* __restrict__ 
   }
 }
 
+// dQ, vector form (h % 8 == 0, h <= 1024): 128 threads, thread t owns dims 8t .. 8t+7 and reads them with one 16-byte
+// load per row (16-bit inputs) -- the scalar form above moves 2 bytes per lane per load.
+template <int DT>
+__global__ void __launch_bounds__(128) k_maxsim_bwd_dq_v8(const void* __restrict__ D, const void* __restrict__ q_mask,
+                                                          const void* __restrict__ d_mask, int mask_dtype,
+                                                          const int32_t* __restrict__ argmax,
+                                                          const float* __restrict__ grad, float* __restrict__ dQ,
+                                                          int nd, int Lq, int Ld, int h) {
+  const int qm = blockIdx.x;
+  const int q = qm / Lq;
+  const int m = qm - q * Lq;
+  const int lane = threadIdx.x & 63;
+  const int k0 = threadIdx.x * 8;
+  const bool act = k0 < h;
+  const float qs = mask_dtype != MAXSIM_MASK_NONE ? load_mask(q_mask, mask_dtype, qm) : 1.0f;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int d0 = 0; d0 < nd; d0 += 64) {
+    const int d = d0 + lane;
+    int64_t row = 0;
+    float g = 0.0f;
+    if (d < nd) {
+      const int i = argmax[((int64_t)q * nd + d) * Lq + m];
+      row = (int64_t)d * Ld + i;
+      g = grad[(int64_t)q * nd + d];
+      if (mask_dtype != MAXSIM_MASK_NONE) g *= load_mask(d_mask, mask_dtype, row);
+    }
+    for (int j0 = 0; j0 < 64; j0 += 4) {  // 4 docs' rows in flight
+      if (d0 + j0 >= nd) break;
+      float gj[4], x[4][8];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        gj[t] = lane_f32(g, j0 + t);
+        const int64_t base = (((int64_t)__builtin_amdgcn_readlane((int)(row >> 32), j0 + t) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)row, j0 + t)) * h;
+        if (act) load8<DT>(D, base + k0, x[t]);
+      }
+      if (act) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc[u] = fmaf(gj[t], x[t][u], acc[u]);
+      }
+    }
+  }
+  if (act) {
+    float* o = dQ + (int64_t)qm * h + k0;
+    *(f32x4*)o = f32x4{acc[0] * qs, acc[1] * qs, acc[2] * qs, acc[3] * qs};
+    *(f32x4*)(o + 4) = f32x4{acc[4] * qs, acc[5] * qs, acc[6] * qs, acc[7] * qs};
+  }
+}
+
 // dD: one workgroup (16 waves) per (doc d, 64-dim chunk); the doc's [Ld][64] fp32 gradient slab lives in LDS and
 // is written out once -- no global atomics, no read-modify-write of dD.  LDS float atomics are very slow on gfx950
 // (~170 cycles per wave-instruction measured), so the slab rows are OWNED: wave w accumulates only the items whose
@@ -129,6 +198,125 @@ __global__ void __launch_bounds__(1024) k_maxsim_bwd_dd_lds(const void* __restri
   for (int i = threadIdx.x; i < Ld * 64; i += 1024) {
     const int n = i >> 6, kk = k0 + (i & 63);
     if (kk < h) dD[((int64_t)d * Ld + n) * h + kk] = slab[i];
+  }
+}
+
+// ---- dD through a per-doc inverse index (needs a caller-provided workspace) ------------------------------------
+// Step 1, one workgroup per doc: the (q, m) items that contribute to the doc (coefficient != 0) are counting-sorted by
+// their arg-max token; inside a token's bucket they are then put in ascending item order, so the sums below have a
+// fixed order (bitwise reproducible).  ws_start[d][0..Ld] = bucket offsets, ws_items[d][*] = item ids.
+__global__ void __launch_bounds__(1024) k_maxsim_bwd_index(const void* __restrict__ q_mask,
+                                                           const void* __restrict__ d_mask, int mask_dtype,
+                                                           const int32_t* __restrict__ argmax,
+                                                           const float* __restrict__ grad, int32_t* __restrict__ ws_start,
+                                                           int32_t* __restrict__ ws_items, int nq, int nd, int Lq,
+                                                           int Ld) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  uint32_t* cnt = (uint32_t*)lds;        // [Ld + 1]: histogram, then running write positions
+  uint32_t* beg = cnt + (Ld + 1);        // [Ld + 1]: bucket starts
+  int32_t* litems = (int32_t*)(beg + (Ld + 1));  // [nitem]: the doc's item list, built and sorted in LDS
+  const int d = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  const int nitem = nq * Lq;
+  for (int i = tid; i <= Ld; i += nt) cnt[i] = 0;
+  __syncthreads();
+  auto key_of = [&](int it) -> int {  // arg-max token of item `it`, or -1 if it contributes nothing
+    const int q = it / Lq, m = it - q * Lq;
+    const int n = argmax[((int64_t)q * nd + d) * Lq + m];
+    float c = grad[(int64_t)q * nd + d];
+    if (mask_dtype != MAXSIM_MASK_NONE)
+      c *= load_mask(q_mask, mask_dtype, it) * load_mask(d_mask, mask_dtype, (int64_t)d * Ld + n);
+    return c != 0.0f ? n : -1;
+  };
+  for (int it = tid; it < nitem; it += nt) {
+    const int k = key_of(it);
+    if (k >= 0) atomicAdd(&cnt[k], 1u);
+  }
+  __syncthreads();
+  if (tid == 0) {  // exclusive scan (Ld is a few hundred)
+    uint32_t run = 0;
+    for (int n = 0; n < Ld; ++n) { beg[n] = run; run += cnt[n]; cnt[n] = 0; }
+    beg[Ld] = run;
+  }
+  __syncthreads();
+  for (int i = tid; i <= Ld; i += nt) ws_start[(int64_t)d * (Ld + 1) + i] = (int32_t)beg[i];
+  for (int it = tid; it < nitem; it += nt) {
+    const int k = key_of(it);
+    if (k >= 0) litems[beg[k] + atomicAdd(&cnt[k], 1u)] = it;
+  }
+  __syncthreads();
+  for (int n = tid; n < Ld; n += nt) {  // fixed order inside each bucket: insertion sort (buckets are short)
+    int32_t* b = litems + beg[n];
+    const int len = (int)(beg[n + 1] - beg[n]);
+    for (int i = 1; i < len; ++i) {
+      const int32_t v = b[i];
+      int j = i - 1;
+      while (j >= 0 && b[j] > v) { b[j + 1] = b[j]; --j; }
+      b[j + 1] = v;
+    }
+  }
+  __syncthreads();
+  const int total = (int)beg[Ld];
+  for (int i = tid; i < total; i += nt) ws_items[(int64_t)d * nitem + i] = litems[i];
+}
+
+// Step 2, one wave per doc token (row of dD): dD[d, n, :] = d_mask * sum over the row's items of g * q_mask * Q[item, :].
+// Lanes cover the hidden dimension (lane + 64 j); 64 items' coefficients are prepared in lanes and walked with readlane.
+template <int DT>
+__global__ void __launch_bounds__(256) k_maxsim_bwd_dd_rows(const void* __restrict__ Q, const void* __restrict__ q_mask,
+                                                            const void* __restrict__ d_mask, int mask_dtype,
+                                                            const float* __restrict__ grad,
+                                                            const int32_t* __restrict__ ws_start,
+                                                            const int32_t* __restrict__ ws_items,
+                                                            float* __restrict__ dD, int nq, int nd, int Lq, int Ld,
+                                                            int h) {
+  // lanes cover the hidden dimension 8 dims at a time: lane l owns dims 512 j + 8 l .. + 7 (j = 0, 1; h <= 1024, h % 8 == 0)
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // d * Ld + n
+  if (row >= (int64_t)nd * Ld) return;
+  const int d = (int)(row / Ld), n = (int)(row - (int64_t)d * Ld);
+  const int nitem = nq * Lq;
+  const int s = ws_start[(int64_t)d * (Ld + 1) + n], e = ws_start[(int64_t)d * (Ld + 1) + n + 1];
+  const int32_t* items = ws_items + (int64_t)d * nitem;
+  const float ds = mask_dtype != MAXSIM_MASK_NONE ? load_mask(d_mask, mask_dtype, row) : 1.0f;
+  const int ka = 8 * lane, kb = 512 + 8 * lane;
+  const bool acta = ka < h, actb = kb < h;
+  float acc[2][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[0][j] = acc[1][j] = 0.0f;
+  for (int p0 = s; p0 < e; p0 += 64) {
+    int it = 0;
+    float c = 0.0f;
+    if (p0 + lane < e) {
+      it = items[p0 + lane];
+      const int q = it / Lq;
+      c = grad[(int64_t)q * nd + d] * ds;
+      if (mask_dtype != MAXSIM_MASK_NONE) c *= load_mask(q_mask, mask_dtype, it);
+    }
+    const int cnt = min(64, e - p0);
+    for (int j0 = 0; j0 < cnt; j0 += 2) {  // two items' rows in flight
+      const int i0 = __builtin_amdgcn_readlane(it, j0), i1 = __builtin_amdgcn_readlane(it, min(j0 + 1, cnt - 1));
+      const float c0 = lane_f32(c, j0), c1 = (j0 + 1 < cnt) ? lane_f32(c, j0 + 1) : 0.0f;
+      float x0a[8], x1a[8], x0b[8], x1b[8];
+      if (acta) { load8<DT>(Q, (int64_t)i0 * h + ka, x0a); load8<DT>(Q, (int64_t)i1 * h + ka, x1a); }
+      if (actb) { load8<DT>(Q, (int64_t)i0 * h + kb, x0b); load8<DT>(Q, (int64_t)i1 * h + kb, x1b); }
+      if (acta) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[0][j] = fmaf(c1, x1a[j], fmaf(c0, x0a[j], acc[0][j]));
+      }
+      if (actb) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[1][j] = fmaf(c1, x1b[j], fmaf(c0, x0b[j], acc[1][j]));
+      }
+    }
+  }
+  float* o = dD + row * h;
+  if (acta) {
+    *(f32x4*)(o + ka) = f32x4{acc[0][0], acc[0][1], acc[0][2], acc[0][3]};
+    *(f32x4*)(o + ka + 4) = f32x4{acc[0][4], acc[0][5], acc[0][6], acc[0][7]};
+  }
+  if (actb) {
+    *(f32x4*)(o + kb) = f32x4{acc[1][0], acc[1][1], acc[1][2], acc[1][3]};
+    *(f32x4*)(o + kb + 4) = f32x4{acc[1][4], acc[1][5], acc[1][6], acc[1][7]};
   }
 }
 

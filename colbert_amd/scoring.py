@@ -75,9 +75,17 @@ class _MaxSimFn(torch.autograd.Function):
         g32 = g.to(device=dev, dtype=torch.float32).contiguous()
         dQ = torch.empty(nq, Lq, h, dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
         dD = torch.empty(nd, Ld, h, dtype=torch.float32, device=dev) if ctx.needs_input_grad[1] else None
+        ws, ws_bytes = None, 0
+        if dD is not None:
+            ws_bytes = int(_lib.lib.maxsim_score_dense_bwd_workspace(nq, nd, Lq, Ld))
+            if 0 < ws_bytes <= (2 << 30):       # per-doc inverse index scratch
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            else:
+                ws_bytes = 0
         with torch.cuda.device(dev):
             rc = _lib.lib.maxsim_score_dense_bwd(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), _ptr(arg), _ptr(g32), nq, nd, Lq,
-                                                 Ld, h, _DT[cdt], _MDT[mdt], _ptr(dQ), _ptr(dD), _stream(dev))
+                                                 Ld, h, _DT[cdt], _MDT[mdt], _ptr(dQ), _ptr(dD), _ptr(ws), ws_bytes,
+                                                 _stream(dev))
         _lib.check(rc, "maxsim_score_dense_bwd")
         return (None if dQ is None else dQ.to(qdt)), (None if dD is None else dD.to(ddt)), None, None
 

@@ -87,7 +87,7 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
  *     dQ[q,m,:] = q_mask[q,m] * sum_d g[q,d] * d_mask[d,i] * D[d,i,:]        i = argmax[q,d,m]
  *     dD[d,i,:] += d_mask[d,i] * g[q,d] * q_mask[q,m] * Q[q,m,:]
  *   argmax [nq, nd, Lq] int32;  grad_out [nq, nd] float32;  dQ [nq, Lq, h], dD [nd, Ld, h] float32 (either may be NULL;
- *   both are fully overwritten).  fp32 accumulation; dD is summed per doc in LDS in a fixed order (reproducible; very long docs fall back to global float atomics).
+ *   both are fully overwritten).  fp32 accumulation in a fixed order (reproducible) except in the global-atomics fallback.
  * h <= 1024 for the backward.
  */
 int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
@@ -95,7 +95,12 @@ int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, con
                            void* stream);
 int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, const void* d_mask,
                            const int32_t* argmax, const float* grad_out, int nq, int nd, int Lq, int Ld, int h,
-                           int dtype, int mask_dtype, float* dQ, float* dD, void* stream);
+                           int dtype, int mask_dtype, float* dQ, float* dD, void* workspace, int64_t workspace_bytes,
+                           void* stream);
+/* Bytes of device scratch with which maxsim_score_dense_bwd computes dD through a per-doc inverse index (fastest,
+ * reproducible).  workspace may be NULL / smaller: dD then falls back to an LDS slab per doc (or, for very long docs,
+ * global float atomics). */
+int64_t maxsim_score_dense_bwd_workspace(int nq, int nd, int Lq, int Ld);
 
 /*
  * Fused ragged rerank, the body of rank_forward (colbert_ranker.py:88-118) for a batch of queries, with the
