@@ -624,3 +624,26 @@ def test_sharded_ranker_local_leg_on_gpu(ca):
         assert tp[qi, :n].tolist() == [p + lo for p in ep]
         np.testing.assert_allclose(ts[qi, :n].cpu().numpy(), np.array(es), rtol=0, atol=ATOL32)
         assert bool((tp[qi, n:] == -1).all()) and bool((ts[qi, n:] == float("-inf")).all())
+
+
+def test_against_plain_c_oracle(ca):
+    """The HIP path against the plain-C restatement (no torch, no BLAS, double accumulation): every index dtype."""
+    from oracle import c_oracle
+    gen = torch.Generator().manual_seed(41)
+    doclens = torch.randint(0, 70, (40,), generator=gen).tolist()
+    doclens[3] = 0
+    emb = nrm(gen, sum(doclens), 128)
+    Q = nrm(gen, 2, 32, 128)
+    cand = torch.stack([torch.randperm(40, generator=gen)[:25] for _ in range(2)])
+    for dt, atol in ((torch.float32, ATOL32), (torch.float16, ATOL32), (torch.bfloat16, ATOL32)):
+        idx = emb.to(dt)
+        r = ca.ColbertRanker(parts=[idx], parts_doclens=[doclens], dim=128, index_dtype=dt)
+        sc = r.score_candidates(Q, cand).cpu().double().numpy()
+        offs = r.doclens_pfxsum[:-1].numpy()
+        for qi in range(2):
+            exp = c_oracle.rerank_one(idx.float().numpy(), offs, np.array(doclens), r.d_pad_len.cpu().numpy(),
+                                      Q[qi].numpy(), cand[qi].numpy())
+            np.testing.assert_allclose(sc[qi], exp, rtol=0, atol=atol)
+    out = ca.score(Q.cuda(), emb[:60].view(3, 20, 128).cuda(), torch.ones(2, 32).cuda(), torch.ones(3, 20).cuda()).cpu().double().numpy()
+    exp = c_oracle.score_dense(Q.numpy(), emb[:60].view(3, 20, 128).numpy(), np.ones((2, 32)), np.ones((3, 20)))
+    np.testing.assert_allclose(out, exp, rtol=0, atol=ATOL32)

@@ -109,3 +109,26 @@ def test_percentile_and_keep_nonzero():
     Q = torch.arange(12.).view(4, 3)
     q, m = keep_nonzero(Q, torch.tensor([1, 0, 1, 0]))
     assert q.tolist() == [[0, 1, 2], [6, 7, 8]] and m.tolist() == [1, 1]
+
+
+# ---- the plain-C restatement (oracle/maxsim_oracle.c), independent of torch/BLAS ---------------------------------
+def test_c_oracle_against_goldens_and_torch_oracle(golden):
+    from oracle import c_oracle
+    g = golden("kat_test_score")
+    assert c_oracle.score_dense(g["Q"].numpy(), g["D"].numpy(), g["q_mask"].numpy(), g["d_mask"].numpy()).tolist() == [[21.0, 41.0]]
+    g = golden("zero_floor")
+    assert c_oracle.score_dense(g["Q"].numpy(), g["D"].numpy(), g["q_mask"].numpy(), g["d_mask_floor"].numpy()).item() == 0.0
+    assert c_oracle.score_dense(g["Q"].numpy(), g["D"].numpy(), g["q_mask"].numpy(), g["d_mask_full"].numpy()).item() == -1.0
+    for name in ("allpairs_4x6_masked", "allpairs_4x6_floatmask", "c4_multiview"):
+        g = golden(name)
+        out = c_oracle.score_dense(g["Q"].numpy(), g["D"].numpy(), g["q_mask"].numpy(), g["d_mask"].numpy())
+        np.testing.assert_allclose(out, g["expected"].numpy(), rtol=0, atol=2e-5)
+    # ragged closed form == the reference's bucket / pad / mask flow (golden generated through the imported score)
+    g = golden("ragged_rerank_64")
+    index = torch.cat([g["part0"], g["part1"]]).float().numpy()
+    doclens = torch.cat([g["doclens0"], g["doclens1"]]).numpy()
+    offs = np.concatenate([[0], np.cumsum(doclens)[:-1]])
+    for key, exp in (("Q", "expected_scores"), ("Q_neg", "expected_scores_neg")):
+        q = g[key][0].permute(1, 0).contiguous().numpy()
+        out = c_oracle.rerank_one(index, offs, doclens, g["pad_len"].numpy(), q, g["pids"].numpy())
+        np.testing.assert_allclose(out, g[exp].numpy(), rtol=0, atol=2e-5)
