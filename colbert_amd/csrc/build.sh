@@ -1,8 +1,18 @@
 #!/bin/bash
-# Builds colbert_amd/libmaxsim.so for gfx950 (cross-compiles without a GPU).
+# Builds colbert_amd/libmaxsim.so for gfx950 (cross-compiles without a GPU).  The translation units are compiled in
+# parallel and linked into one shared library.
 set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-"$HIPCC" -O3 --offload-arch=gfx950 -std=c++17 -I"$ROOT/include" -shared -fPIC \
-    -I"$HERE" "$HERE/maxsim.hip" -o "$ROOT/colbert_amd/libmaxsim.so" "$@"
+OBJ="$ROOT/build/obj"
+mkdir -p "$OBJ"
+FLAGS=(-O3 --offload-arch=gfx950 -std=c++17 -I"$ROOT/include" -I"$HERE" -fPIC "$@")
+pids=()
+for tu in maxsim tu_stream tu_bigh_rerank tu_bigh_dense tu_bigh_dense_am; do
+  "$HIPCC" "${FLAGS[@]}" -c "$HERE/$tu.hip" -o "$OBJ/$tu.o" &
+  pids+=($!)
+done
+for p in "${pids[@]}"; do wait "$p"; done
+"$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/maxsim.o "$OBJ"/tu_stream.o "$OBJ"/tu_bigh_rerank.o \
+    "$OBJ"/tu_bigh_dense.o "$OBJ"/tu_bigh_dense_am.o -o "$ROOT/colbert_amd/libmaxsim.so"

@@ -3,146 +3,20 @@
 // What is computed (reference: wuyaoxuehun/colbert, colbert/modeling/BaseModel.py:39-46 and
 // colbert/ranking/colbert_ranker.py:88-118):
 //     score(q, doc) = sum_m  max_n  <Q[q,m,:], D[doc,n,:]>
-// Kernels: maxsim_stream.h (MFMA + LDS-DMA streaming kernel, the hot path), maxsim_generic.h (any-shape
-// correctness kernel), maxsim_topk.h (per-query top-k).  This file holds the launch heuristics and the C ABI
-// declared in include/maxsim.h.  gfx950 only: no CUDA, no hipify, no dual paths.
+// Kernels: maxsim_stream.h / maxsim_stream_bigh.h (MFMA + LDS-DMA streaming kernels, the hot path; compiled in the
+// tu_*.hip units so that they build in parallel), maxsim_generic.h (any-shape correctness kernel), maxsim_topk.h,
+// maxsim_candidates.h, maxsim_backward.h.  This file holds the dispatch and the C ABI declared in include/maxsim.h.
+// gfx950 only: no CUDA, no hipify, no dual paths.
 #include "maxsim_backward.h"
 #include "maxsim_candidates.h"
 #include "maxsim_common.h"
 #include "maxsim_generic.h"
-#include "maxsim_stream.h"
-#include "maxsim_stream_bigh.h"
+#include "maxsim_launch.h"
 #include "maxsim_topk.h"
 
 using namespace maxsim;
 
 namespace {
-
-template <typename K>
-int allow_lds(K kernel, int bytes) {
-  if (bytes <= 64 * 1024) return MAXSIM_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
-}
-
-int check_launch() { return hipGetLastError() == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH; }
-
-int env_int(const char* name, int dflt) {
-  const char* e = getenv(name);
-  return e ? atoi(e) : dflt;
-}
-
-// Docs per wave for the streaming kernel: a wave's token stream should be long enough (~1.5k tokens) that the
-// one partly filled last tile and the 16 KiB query-tile load are noise, short enough that the grid covers the
-// 256 CUs several times over.  At most 64 docs per wave (scores are parked one per lane).
-int pick_docs_per_wave(const Params& p, int waves) {
-  double avg = p.n_docs > 0 ? (double)p.n_tokens / (double)p.n_docs : 1.0;
-  if (avg < 1.0) avg = 1.0;
-  int dpwv = (int)(1440.0 / avg + 0.5);
-  if (dpwv < 1) dpwv = 1;
-  if (dpwv > 64) dpwv = 64;
-  while (dpwv > 1 && (int64_t)p.nq * ((p.ncand + dpwv * waves - 1) / (dpwv * waves)) < 2048) dpwv = (dpwv + 1) / 2;
-  return dpwv;
-}
-
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>
-int launch_stream_v(Params& p, hipStream_t st) {
-  int dpwv = env_int("MAXSIM_DPW", 0);  // tuning knob: docs per wave
-  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
-  p.dpw = dpwv * WAVES;
-  p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
-  const int ldsb = WAVES * NT * StreamTraits<DT>::TILE;
-  auto kern = k_maxsim_stream<MODE, DT, WAVES, NT, ABLATE, QT>;
-  int rc = allow_lds(kern, ldsb);
-  if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
-  return check_launch();
-}
-
-// Per-wave LDS ring: fp32 1 x 16 KiB tile, 16-bit 2 x 8 KiB tiles; 4 waves per workgroup = 64 KiB, two
-// workgroups per CU.  MAXSIM_VARIANT is a diagnostic knob (DESIGN.md "Tuning knobs"): 1/2 = ablation builds.
-template <int MODE, int DT>
-int launch_stream(Params& p, hipStream_t st) {
-  constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
-  if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {  // <= 16 query tokens: the 16-column f32 MFMA form
-    const int v16 = env_int("MAXSIM_VARIANT", 0);
-    if (p.Lq <= 16 && v16 != 4) {  // (Lq <= 16 implies a single query slice)
-      if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
-      if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
-      return launch_stream_v<MODE, DT, 4, NT0, 0, 16>(p, st);
-    }
-  }
-  switch (env_int("MAXSIM_VARIANT", 0)) {
-    case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)
-    case 2: return launch_stream_v<MODE, DT, 4, NT0, 2>(p, st);  // no DMA   (timing only, wrong results)
-    case 3: return launch_stream_v<MODE, DT, 4, NT0 * 2>(p, st); // deeper ring, 1 workgroup per CU
-    default: return launch_stream_v<MODE, DT, 4, NT0>(p, st);
-  }
-}
-
-// Query-in-LDS streaming kernel (h = 128 * KB): QB query images of NPQ x KB x sub-tile bytes each, the rest of the
-// 160 KiB goes to the waves' rings: as many waves (<= 8) as fit with NT sub-tiles each.
-template <int MODE, int DT, int NPQ, bool AM, int QB, bool PART = false>
-int launch_stream_bigh_q(Params& p, hipStream_t st) {
-  constexpr int SUB = StreamTraits<DT>::TILE;
-  const int KB = (p.h + 127) / 128;
-  const int qbytes = QB * NPQ * KB * SUB;
-  const int avail = 160 * 1024 - qbytes;
-  int dpwv = env_int("MAXSIM_DPW", 0);
-  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4);
-  auto go = [&](auto kern, int waves, int nt) {
-    p.dpw = dpwv * waves;
-    p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
-    const int ldsb = qbytes + waves * nt * SUB;
-    int rc = allow_lds(kern, ldsb);
-    if (rc) return rc;
-    const int nqblk = (p.nq + QB - 1) / QB;
-    hipLaunchKernelGGL(kern, dim3((unsigned)(nqblk * p.nchunk)), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
-    return check_launch();
-  };
-  if constexpr (PART) {  // odd widths: one configuration (keeps the number of instantiations down)
-    if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB, true>, 4, 1);
-    return MAXSIM_ERANGE;
-  } else {
-    if constexpr (QB == 1) {
-      if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
-      if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
-    } else {  // several queries per workgroup: the matrix work per sub-tile is QB x longer, one sub-tile ahead suffices
-      if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
-    }
-    if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB>, 4, 1);
-    return MAXSIM_ERANGE;
-  }
-}
-
-// All-pairs (dense) launches share each doc sub-tile between QB queries of a workgroup: the largest QB whose query
-// images leave room for >= 4 waves x 1 sub-tile and whose accumulators (16 VGPRs per query and piece) stay <= 64
-// (QB = 8 spills).
-template <int MODE, int DT, int NPQ, bool AM>
-int launch_stream_bigh(Params& p, hipStream_t st) {
-  if (p.h & 127) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 1, true>(p, st);  // partial last block
-  if constexpr (MODE == MODE_DENSE) {
-    constexpr int SUB = StreamTraits<DT>::TILE;
-    const int qimg = NPQ * (p.h / 128) * SUB;
-    const int qb_env = env_int("MAXSIM_QB", 0);  // tuning knob
-    auto fits = [&](int qb) { return qb * qimg + 4 * SUB <= 160 * 1024 && qb * NPQ <= 4 && (qb_env == 0 || qb <= qb_env); };
-    if (p.nq >= 4 && fits(4)) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 4>(p, st);
-    if (p.nq >= 2 && fits(2)) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 2>(p, st);
-  }
-  return launch_stream_bigh_q<MODE, DT, NPQ, AM, 1>(p, st);
-}
-
-template <int MODE, bool AM>
-int launch_bigh(Params& p, int dt, hipStream_t st) {
-  const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;  // query already in the index's 16-bit type: one piece
-  switch (dt) {
-    case MAXSIM_F32: return launch_stream_bigh<MODE, MAXSIM_F32, 1, AM>(p, st);
-    case MAXSIM_F16:
-      return same16 ? launch_stream_bigh<MODE, MAXSIM_F16, 1, AM>(p, st) : launch_stream_bigh<MODE, MAXSIM_F16, 2, AM>(p, st);
-    default:
-      return same16 ? launch_stream_bigh<MODE, MAXSIM_BF16, 1, AM>(p, st) : launch_stream_bigh<MODE, MAXSIM_BF16, 2, AM>(p, st);
-  }
-}
 
 // Queries longer than 32 tokens: score(Q) = sum over 32-token slices of score(slice) (the sum over query tokens
 // is additive), one launch per slice, the later ones accumulating into `scores`.
@@ -224,11 +98,11 @@ static int score_dense_impl(const void* Q, const void* D, const void* q_mask, co
   p.Ld = Ld;
   const bool stream_ok = (Lq <= 32 || (!argmax && Lq <= MAX_LQ_SLICED)) && p.n_tokens <= 0xffffffffLL;
   if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128)
-    return for_query_slices(p, [&] { return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st); });
+    return for_query_slices(p, [&] { return launch_stream_dense_f32(p, st); });
   const int esz = dtype == MAXSIM_F32 ? 4 : 2;
   if (stream_ok && h >= 16 && h <= 1024 && ((h * esz) & 15) == 0) {
-    int rc = argmax ? launch_bigh<MODE_DENSE, true>(p, dtype, st)
-                    : for_query_slices(p, [&] { return launch_bigh<MODE_DENSE, false>(p, dtype, st); });
+    int rc = argmax ? launch_bigh_dense(p, dtype, true, st)
+                    : for_query_slices(p, [&] { return launch_bigh_dense(p, dtype, false, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_DENSE>(p, dtype, st);
@@ -346,18 +220,12 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
   p.mask_dtype = MAXSIM_MASK_NONE;
   const bool stream_ok = Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
   if (h == 128 && stream_ok) {
-    return for_query_slices(p, [&] {
-      if (index_dtype == MAXSIM_F32) return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
-      if (index_dtype == MAXSIM_F32_FAST) return launch_stream<MODE_RERANK, MAXSIM_F32_FAST>(p, st);
-      if (index_dtype == MAXSIM_F32_BF16X3) return launch_stream<MODE_RERANK, MAXSIM_F32_BF16X3>(p, st);
-      if (index_dtype == MAXSIM_F16) return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
-      return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
-    });
+    return for_query_slices(p, [&] { return launch_stream_rerank(p, index_dtype, st); });
   }
   const int esz = (index_dtype == MAXSIM_F32 || index_dtype >= MAXSIM_F32_FAST) ? 4 : 2;
   if (h >= 16 && h <= 1024 && ((h * esz) & 15) == 0 && stream_ok) {
     const int dt = index_dtype >= MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype;
-    int rc = for_query_slices(p, [&] { return launch_bigh<MODE_RERANK, false>(p, dt, st); });
+    int rc = for_query_slices(p, [&] { return launch_bigh_rerank(p, dt, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_RERANK>(p, index_dtype >= MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);

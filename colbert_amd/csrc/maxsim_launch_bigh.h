@@ -1,0 +1,74 @@
+// maxsim_launch_bigh.h -- launch heuristics of the LDS-query streaming kernel (included by the two tu_bigh_*.hip units).
+#pragma once
+#include "maxsim_launch.h"
+#include "maxsim_stream_bigh.h"
+
+namespace maxsim {
+namespace {
+
+// Query-in-LDS streaming kernel (h = 128 * KB): QB query images of NPQ x KB x sub-tile bytes each, the rest of the
+// 160 KiB goes to the waves' rings: as many waves (<= 8) as fit with NT sub-tiles each.
+template <int MODE, int DT, int NPQ, bool AM, int QB, bool PART = false>
+int launch_stream_bigh_q(Params& p, hipStream_t st) {
+  constexpr int SUB = StreamTraits<DT>::TILE;
+  const int KB = (p.h + 127) / 128;
+  const int qbytes = QB * NPQ * KB * SUB;
+  const int avail = 160 * 1024 - qbytes;
+  int dpwv = env_int("MAXSIM_DPW", 0);
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4);
+  auto go = [&](auto kern, int waves, int nt) {
+    p.dpw = dpwv * waves;
+    p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+    const int ldsb = qbytes + waves * nt * SUB;
+    int rc = allow_lds(kern, ldsb);
+    if (rc) return rc;
+    const int nqblk = (p.nq + QB - 1) / QB;
+    hipLaunchKernelGGL(kern, dim3((unsigned)(nqblk * p.nchunk)), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
+    return check_launch();
+  };
+  if constexpr (PART) {  // odd widths: one configuration (keeps the number of instantiations down)
+    if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB, true>, 4, 1);
+    return MAXSIM_ERANGE;
+  } else {
+    if constexpr (QB == 1) {
+      if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
+      if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
+    } else {  // several queries per workgroup: the matrix work per sub-tile is QB x longer, one sub-tile ahead suffices
+      if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
+    }
+    if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB>, 4, 1);
+    return MAXSIM_ERANGE;
+  }
+}
+
+// All-pairs (dense) launches share each doc sub-tile between QB queries of a workgroup: the largest QB whose query
+// images leave room for >= 4 waves x 1 sub-tile and whose accumulators (16 VGPRs per query and piece) stay <= 64
+// (QB = 8 spills).
+template <int MODE, int DT, int NPQ, bool AM>
+int launch_stream_bigh(Params& p, hipStream_t st) {
+  if (p.h & 127) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 1, true>(p, st);  // partial last block
+  if constexpr (MODE == MODE_DENSE) {
+    constexpr int SUB = StreamTraits<DT>::TILE;
+    const int qimg = NPQ * (p.h / 128) * SUB;
+    const int qb_env = env_int("MAXSIM_QB", 0);  // tuning knob
+    auto fits = [&](int qb) { return qb * qimg + 4 * SUB <= 160 * 1024 && qb * NPQ <= 4 && (qb_env == 0 || qb <= qb_env); };
+    if (p.nq >= 4 && fits(4)) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 4>(p, st);
+    if (p.nq >= 2 && fits(2)) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 2>(p, st);
+  }
+  return launch_stream_bigh_q<MODE, DT, NPQ, AM, 1>(p, st);
+}
+
+template <int MODE, bool AM>
+int launch_bigh(Params& p, int dt, hipStream_t st) {
+  const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;  // query already in the index's 16-bit type: one piece
+  switch (dt) {
+    case MAXSIM_F32: return launch_stream_bigh<MODE, MAXSIM_F32, 1, AM>(p, st);
+    case MAXSIM_F16:
+      return same16 ? launch_stream_bigh<MODE, MAXSIM_F16, 1, AM>(p, st) : launch_stream_bigh<MODE, MAXSIM_F16, 2, AM>(p, st);
+    default:
+      return same16 ? launch_stream_bigh<MODE, MAXSIM_BF16, 1, AM>(p, st) : launch_stream_bigh<MODE, MAXSIM_BF16, 2, AM>(p, st);
+  }
+}
+
+}  // namespace
+}  // namespace maxsim

@@ -1,0 +1,57 @@
+// tu_stream.hip -- instantiations + launch heuristics of the h = 128 register-query streaming kernel (maxsim_stream.h).
+#include "maxsim_launch.h"
+#include "maxsim_stream.h"
+
+namespace maxsim {
+namespace {
+
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>
+int launch_stream_v(Params& p, hipStream_t st) {
+  int dpwv = env_int("MAXSIM_DPW", 0);  // tuning knob: docs per wave
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
+  p.dpw = dpwv * WAVES;
+  p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+  const int ldsb = WAVES * NT * StreamTraits<DT>::TILE;
+  auto kern = k_maxsim_stream<MODE, DT, WAVES, NT, ABLATE, QT>;
+  int rc = allow_lds(kern, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  return check_launch();
+}
+
+// Per-wave LDS ring: fp32 1 x 16 KiB tile, 16-bit 2 x 8 KiB tiles; 4 waves per workgroup = 64 KiB, two
+// workgroups per CU.  MAXSIM_VARIANT is a diagnostic knob (DESIGN.md "Tuning knobs"): 1/2 = ablation builds.
+template <int MODE, int DT>
+int launch_stream(Params& p, hipStream_t st) {
+  constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
+  if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {  // <= 16 query tokens: the 16-column f32 MFMA form
+    const int v16 = env_int("MAXSIM_VARIANT", 0);
+    if (p.Lq <= 16 && v16 != 4) {  // (Lq <= 16 implies a single query slice)
+      if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
+      if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
+      return launch_stream_v<MODE, DT, 4, NT0, 0, 16>(p, st);
+    }
+  }
+  switch (env_int("MAXSIM_VARIANT", 0)) {
+    case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)
+    case 2: return launch_stream_v<MODE, DT, 4, NT0, 2>(p, st);  // no DMA   (timing only, wrong results)
+    case 3: return launch_stream_v<MODE, DT, 4, NT0 * 2>(p, st); // deeper ring, 1 workgroup per CU
+    default: return launch_stream_v<MODE, DT, 4, NT0>(p, st);
+  }
+}
+
+}  // namespace
+
+int launch_stream_rerank(Params& p, int index_dtype, hipStream_t st) {
+  switch (index_dtype) {
+    case MAXSIM_F32: return launch_stream<MODE_RERANK, MAXSIM_F32>(p, st);
+    case MAXSIM_F32_FAST: return launch_stream<MODE_RERANK, MAXSIM_F32_FAST>(p, st);
+    case MAXSIM_F32_BF16X3: return launch_stream<MODE_RERANK, MAXSIM_F32_BF16X3>(p, st);
+    case MAXSIM_F16: return launch_stream<MODE_RERANK, MAXSIM_F16>(p, st);
+    default: return launch_stream<MODE_RERANK, MAXSIM_BF16>(p, st);
+  }
+}
+
+int launch_stream_dense_f32(Params& p, hipStream_t st) { return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st); }
+
+}  // namespace maxsim
