@@ -109,10 +109,13 @@ def main():
     ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
+    ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (0 = 256, the metric's batch; diagnostic)")
     ap.add_argument("--q-dtype", default="", choices=["", "fp32", "fp16", "bf16"],
                     help="element type the queries are handed over in (default: fp32; c5: bf16)")
     ap.add_argument("--fp32-mode", default="exact", choices=["exact", "fast", "bf16x3"],
                     help="fp32 index only: exact f32 MFMA (default) or the split-fp16 fast mode")
+    ap.add_argument("--ncand", type=int, default=0,
+                    help="candidates per query on each GPU (0 = 1000 / N; diagnostic: --nq 2048 --ncand 125 is one rank's share of N = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the host-side legs (cpu_baseline and the single-query latency probe): profiling runs")
     ap.add_argument("--force-dist", action="store_true",
@@ -161,9 +164,9 @@ def main():
     lo, hi = rank * ndocs, (rank + 1) * ndocs
     sharded = ShardedRanker(ranker, lo, hi)
 
-    nq = NQ * world
-    per = NCAND // world
-    assert per * world == NCAND
+    nq = (args.nq or NQ) * world
+    per = args.ncand or NCAND // world
+    assert args.ncand or per * world == NCAND
     total = args.warmup + args.steps
     gq = torch.Generator(device=dev).manual_seed(1)            # same queries on every rank
     Q = F.normalize(torch.randn(nq, LQ, H, generator=gq, device=dev), dim=-1)
@@ -216,7 +219,7 @@ def main():
     # MI355X_MICROARCH.md prescribes; summary committed under profiles/ by tools/summarize_profile.py)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
-    if world == 1 and ndocs == wl["ndocs"] and not args.lq and os.path.exists(pmc):
+    if world == 1 and ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand) and os.path.exists(pmc):
         try:
             for k, v in json.load(open(pmc)).items():
                 if "k_maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
@@ -231,10 +234,10 @@ def main():
             "value": round(nq * args.steps / el, 2), "unit": "queries/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload.upper()}: {NQ} queries/GPU x {NCAND} candidates/query, {LQ}x"
+            "config": {"workload": f"{args.workload.upper()}: {args.nq or NQ} queries/GPU x {NCAND} candidates/query, {LQ}x"
                                    f"{'~120 (8..180 ragged)' if wl['ragged'] else LD} tokens, dim {H}, "
                                    f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}",
-                       "queries_per_step": nq, "candidates_per_query": NCAND, "docs_per_gpu": ndocs,
+                       "queries_per_step": nq, "candidates_per_query": per * world, "docs_per_gpu": ndocs,
                        "index_dtype": args.index_dtype, "q_dtype": q_dtype, "fp32_mode": args.fp32_mode, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
