@@ -5,7 +5,8 @@ set -euo pipefail
 HERE="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
 ROOT="$(cd "$HERE/../.." && pwd)"
 HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
-OBJ="$ROOT/build/obj"
+OUT="${MAXSIM_OUT:-$ROOT/colbert_amd/libmaxsim.so}"
+OBJ="$ROOT/build/obj$(echo "$OUT" | md5sum | cut -c1-8)"
 mkdir -p "$OBJ"
 FLAGS=(-O3 --offload-arch=gfx950 -std=c++17 -I"$ROOT/include" -I"$HERE" -fPIC "$@")
 pids=()
@@ -15,4 +16,4 @@ for tu in maxsim tu_stream tu_bigh_rerank tu_bigh_dense tu_bigh_dense_am; do
 done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/maxsim.o "$OBJ"/tu_stream.o "$OBJ"/tu_bigh_rerank.o \
-    "$OBJ"/tu_bigh_dense.o "$OBJ"/tu_bigh_dense_am.o -o "$ROOT/colbert_amd/libmaxsim.so"
+    "$OBJ"/tu_bigh_dense.o "$OBJ"/tu_bigh_dense_am.o -o "$OUT"

@@ -568,6 +568,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   int buf = 0;
 
   while (nconsumed < nissued) {
+    __builtin_amdgcn_s_setprio(0);
     // tiles c+1 .. c+NT-1 were issued after this one iff the previous step issued
     if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
     const char* tl = wlds + buf * TILE + rdbase;
@@ -594,6 +595,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       prev_issued = t.kind != 0;
     }
     buf = (buf + 1 == NT) ? 0 : buf + 1;
+    // The contraction + reduce phase runs at raised priority: when both waves of a SIMD hold a tile, the matrix pipe
+    // finishes one of them first (instead of interleaving both), so that wave's next fetch wait starts earlier.
+    __builtin_amdgcn_s_setprio(3);
 
     float mv = 1.0f;
     if constexpr (MODE == MODE_DENSE) {  // D * d_mask[..., None], BaseModel.py:41

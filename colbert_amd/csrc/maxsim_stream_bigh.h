@@ -260,6 +260,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   for (int x = 0; x < (NPQ == 2 ? QB : 1); ++x) acc1[x] = (f32x16)(0.0f);
 
   while (nconsumed < nissued) {
+    __builtin_amdgcn_s_setprio(0);
     if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
     const char* tl = wlds + buf * SUB + rdbase;
     u32x4 a[NRD];
@@ -272,6 +273,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       prev_issued = ok;
     }
     buf = (buf + 1 == NT) ? 0 : buf + 1;
+    __builtin_amdgcn_s_setprio(3);  // contraction phase at raised priority (see maxsim_stream.h)
 
     if constexpr (MODE == MODE_DENSE) {
       if (masked && ckb == 0) {  // first block of a tile: look up the tile's 32 mask values (one per lane pair)
