@@ -109,6 +109,7 @@ def main():
     ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
     ap.add_argument("--lq", type=int, default=0, help="query tokens (0 = the workload's default)")
+    ap.add_argument("--ld", type=int, default=0, help="tokens per doc (0 = the workload's default; diagnostic)")
     ap.add_argument("--nq", type=int, default=0, help="queries per GPU per step (0 = 256, the metric's batch; diagnostic)")
     ap.add_argument("--q-dtype", default="", choices=["", "fp32", "fp16", "bf16"],
                     help="element type the queries are handed over in (default: fp32; c5: bf16)")
@@ -147,7 +148,7 @@ def main():
     from colbert_amd.sharded import ShardedRanker
 
     wl = WORKLOADS[args.workload]
-    LQ, LD, H = (args.lq or wl["lq"]), wl["ld"], wl["h"]
+    LQ, LD, H = (args.lq or wl["lq"]), (args.ld or wl["ld"]), wl["h"]
     args.index_dtype = args.index_dtype or wl["dtype"]
     dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.index_dtype]
     esize = torch.empty(0, dtype=dtype).element_size()
@@ -219,7 +220,7 @@ def main():
     # MI355X_MICROARCH.md prescribes; summary committed under profiles/ by tools/summarize_profile.py)
     traffic = None
     pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
-    if world == 1 and ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand) and os.path.exists(pmc):
+    if world == 1 and ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand or args.ld) and os.path.exists(pmc):
         try:
             for k, v in json.load(open(pmc)).items():
                 if "k_maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
