@@ -354,6 +354,73 @@ def test_c2_full_batch_properties(ca):
     torch.testing.assert_close(s_own.cpu(), torch.full((nq, 1), 32.0), rtol=0, atol=1e-3)
 
 
+@pytest.mark.parametrize("name,L,h,Lq,dtype,ndocs,atol", [
+    ("c4", 8, 128, 8, torch.float32, 200000, ATOL32),       # BASELINE configs[3]: multi-view, 8 viewer tokens per doc
+    ("c4_q32", 8, 128, 32, torch.float32, 200000, ATOL32),  # its secondary form: 32 query tokens
+    ("c5", 256, 768, 32, torch.bfloat16, 6000, ATOL16),     # BASELINE configs[4]: bf16, dim 768, 256 doc tokens
+])
+def test_c4_c5_full_batch_properties(ca, name, L, h, Lq, dtype, ndocs, atol):
+    """256 queries x 1000 candidates at the BASELINE shapes C4 / C5: a sample against the CPU oracle (fp32 on the
+    identically rounded inputs), bitwise invariance to candidate order and batch composition, top-k consistency,
+    self-retrieval (a doc queried with its own first Lq tokens scores ~Lq)."""
+    from oracle.maxsim_oracle import ref_score
+    dev = "cuda"
+    gen = torch.Generator(device=dev).manual_seed(4321)
+    nq, ncand = 256, 1000
+    idx = F.normalize(torch.randn(ndocs * L, h, generator=gen, device=dev), dim=-1).to(dtype)
+    r = ca.ColbertRanker(parts=[idx], parts_doclens=[[L] * ndocs], dim=h, index_dtype=dtype)
+    assert r.strides == [L]
+    Q = F.normalize(torch.randn(nq, Lq, h, generator=gen, device=dev), dim=-1).to(dtype)
+    cand = torch.stack([torch.randperm(ndocs, generator=gen, device=dev)[:ncand] for _ in range(nq)])
+    sc = r.score_candidates(Q, cand)
+    assert sc.shape == (nq, ncand) and sc.dtype == torch.float32 and bool(torch.isfinite(sc).all())
+    D3 = idx.view(ndocs, L, h)
+    for qi in (0, 101, 255):
+        cols = torch.arange(0, ncand, 97, device=dev)
+        Dq = D3[cand[qi, cols]].cpu().float()
+        exp = ref_score(Q[qi:qi + 1].cpu().float(), Dq, torch.ones(1, Lq, dtype=torch.long),
+                        torch.ones(len(cols), L, dtype=torch.long))[0]
+        torch.testing.assert_close(sc[qi, cols].cpu(), exp, rtol=0, atol=atol)
+    perm = torch.randperm(ncand, generator=gen, device=dev)
+    assert torch.equal(r.score_candidates(Q, cand[:, perm]), sc[:, perm])
+    assert torch.equal(r.score_candidates(Q[7:10], cand[7:10, :130]), sc[7:10, :130])
+    tp, ts = r.rerank_batch(Q, cand, depth=100)
+    es, ei = torch.sort(sc, dim=1, descending=True, stable=True)
+    assert torch.equal(ts, es[:, :100]) and torch.equal(tp, torch.gather(cand, 1, ei[:, :100]))
+    lq_own = min(Lq, L)
+    own = D3[cand[:, 0], :lq_own].contiguous()
+    s_own = r.score_candidates(own, cand[:, :1])
+    torch.testing.assert_close(s_own.cpu(), torch.full((nq, 1), float(lq_own)), rtol=0, atol=0.05 if dtype != torch.float32 else 1e-3)
+
+
+@pytest.mark.parametrize("index_dtype", [torch.float32, torch.float16])
+def test_rerank_bsize_candidates(ca, index_dtype):
+    """The reference's largest candidate list: BSIZE = 16384 = 32 query tokens x faiss_depth 512 (colbert_ranker.py:11),
+    ragged docs, duplicates and padding slots included; full score vector against the oracle's closed form on a
+    sample, top-k against torch.sort on the GPU scores."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(16384)
+    ndocs = 3000
+    doclens = torch.randint(1, 181, (ndocs,), generator=gen).tolist()
+    part = nrm(gen, sum(doclens), 128).to(index_dtype)
+    r = ca.ColbertRanker(parts=[part], parts_doclens=[doclens], dim=128, index_dtype=index_dtype)
+    Q = nrm(gen, 2, 32, 128)
+    cand = torch.randint(0, ndocs, (2, 16384), generator=gen)
+    cand[0, 5] = -1
+    cand[1, 16383] = ndocs + 7
+    sc = r.score_candidates(Q, cand).cpu()
+    assert sc[0, 5] == float("-inf") and sc[1, 16383] == float("-inf")
+    cols = list(range(0, 16383, 331)) + [16382]
+    for qi in range(2):
+        pids = [int(cand[qi, c]) for c in cols if c != 5]
+        e = ragged_scores_f64(part.float(), doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi], pids)
+        got = torch.tensor([sc[qi, c].item() for c in cols if c != 5], dtype=torch.float64)
+        assert float((got - torch.as_tensor(e, dtype=torch.float64)).abs().max()) <= (ATOL32 if index_dtype == torch.float32 else ATOL16)
+    tp, ts = r.rerank_batch(Q, cand, depth=100)
+    es, ei = torch.sort(sc, dim=1, descending=True, stable=True)
+    assert torch.equal(ts.cpu(), es[:, :100]) and torch.equal(tp.cpu(), torch.gather(cand, 1, ei[:, :100]))
+
+
 # ------------------------------------------------------------------------------------------------------
 # candidate-side glue: colbert_ranker.py:163-174 (emb2pid) + :212-229 (per-query set())
 # ------------------------------------------------------------------------------------------------------
