@@ -361,6 +361,78 @@ struct Reducer16 {
   }
 };
 
+// Reducer for 32 query tokens held as TWO 16-column blocks of v_mfma_f32_16x16x4_f32 (QT_2X16): lane = query token
+// 16 cb + (lane & 15) of block cb x row quarter g = lane >> 4; sv[cb][4 b + v] = similarity with tile row 16 b + 4 g + v.
+struct Reducer2x16 {
+  float rmax0, rmax1, myscore;
+  int jdoc;
+  __device__ __forceinline__ void init() {
+    rmax0 = rmax1 = NEG_INF;
+    myscore = 0.0f;
+    jdoc = 0;
+  }
+  __device__ __forceinline__ void finish_doc(const Cursor& C, int lane) {
+    float sc;
+    if (C.kind == 0) {
+      // quarters g, g + 2 (lane halves): one swap leaves block 0 in the lower half, block 1 in the upper half
+      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax0), __float_as_uint(rmax1), false, false);
+      float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      // quarters g, g + 1 (adjacent rows of 16 lanes)
+      const uint32_t xb = __float_as_uint(v);
+      const auto s16 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+      v = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+      if (C.floor0) v = fmaxf(v, 0.0f);
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      v += dpp_f32<0x141>(v);
+      v += dpp_f32<0x140>(v);  // 16-lane row sums: row 0 = query tokens 0..15, row 2 = tokens 16..31
+      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+           __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    } else {
+      sc = C.kind == 1 ? 0.0f : NEG_INF;
+    }
+    myscore = (lane == jdoc) ? sc : myscore;
+    ++jdoc;
+    rmax0 = rmax1 = NEG_INF;
+  }
+  __device__ __forceinline__ void reduce_tile(const float (&sv)[2][8], Cursor& C, const DocLanes& dl, int lane) {
+    const int g4 = 4 * (lane >> 4);
+    int filled = 0;
+    while (filled < 32 && C.valid) {
+      const int take = uni(min(32 - filled, max(C.len - C.pos, 0)));
+      if (take == 32) {
+        rmax0 = fmaxf(rmax0, fmaxf(fmaxf(fmaxf(sv[0][0], sv[0][1]), fmaxf(sv[0][2], sv[0][3])),
+                                   fmaxf(fmaxf(sv[0][4], sv[0][5]), fmaxf(sv[0][6], sv[0][7]))));
+        rmax1 = fmaxf(rmax1, fmaxf(fmaxf(fmaxf(sv[1][0], sv[1][1]), fmaxf(sv[1][2], sv[1][3])),
+                                   fmaxf(fmaxf(sv[1][4], sv[1][5]), fmaxf(sv[1][6], sv[1][7]))));
+      } else if (take > 0) {
+        float m0 = NEG_INF, m1 = NEG_INF;
+        const uint32_t lo = (uint32_t)(filled - g4), n_in = (uint32_t)take;
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const bool in = ((uint32_t)(16 * (v >> 2) + (v & 3)) - lo) < n_in;
+          m0 = fmaxf(m0, in ? sv[0][v] : NEG_INF);
+          m1 = fmaxf(m1, in ? sv[1][v] : NEG_INF);
+        }
+        rmax0 = fmaxf(rmax0, m0);
+        rmax1 = fmaxf(rmax1, m1);
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {
+        finish_doc(C, lane);
+        C.next_doc(dl);
+      }
+    }
+  }
+  __device__ __forceinline__ void drain(Cursor& C, const DocLanes& dl, int lane) {
+    while (C.valid) {
+      finish_doc(C, lane);
+      C.next_doc(dl);
+    }
+  }
+};
+
 // Reduction state that also tracks WHERE each query token's maximum sits (training-form forward: the backward pass
 // routes gradients through the arg-max token, torch.max semantics = first maximal index).  Dense mode only.
 struct ReducerArg {
@@ -421,12 +493,13 @@ struct ReducerArg {
   }
 };
 
+constexpr int QT_2X16 = 48;  // 32 query tokens as two 16-column blocks of v_mfma_f32_16x16x4_f32
 // QT = 16: at most 16 query tokens (e.g. the multi-view configs, dense.yaml q_view): fp32 index on
 // v_mfma_f32_16x16x4_f32 -- half the matrix-pipe time of the 32-column form, half the query registers.
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
-  static_assert(QT == 32 || (QT == 16 && DT == MAXSIM_F32 && MODE == MODE_RERANK), "16-column form: fp32 rerank only");
+  static_assert(QT == 32 || ((QT == 16 || QT == QT_2X16) && DT == MAXSIM_F32 && MODE == MODE_RERANK), "16-column forms: fp32 rerank only");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   using T = StreamTraits<DT>;
@@ -484,17 +557,25 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     const int64_t qoff = ((int64_t)qi * p.Lq + (live ? qtok : 0)) * 128;
     const float* qrow = (const float*)p.Q + qoff;
     const bool qf32 = p.q_dtype == MAXSIM_F32;  // a 16-bit query is widened element by element (start-up only)
-    if constexpr (QT == 16) {
-      // lane (n = lane & 15, kq = lane >> 4) holds Q[n][16 j + 4 kq + t] in qv[j][t], j = 0..7
+    if constexpr (QT != 32) {
+      // lane (n = lane & 15, kq = lane >> 4) holds Q[16 cb + n][16 j + 4 kq + t] in qv[8 cb + j][t], j = 0..7
       const int n16 = lane & 15, kq = lane >> 4;
-      const bool live16 = p.q_tok0 + n16 < qlen;
-      const int64_t qo = ((int64_t)qi * p.Lq + (live16 ? p.q_tok0 + n16 : 0)) * 128;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        f32x4 v;
+      for (int cb = 0; cb < (QT == 16 ? 1 : 2); ++cb) {
+        const int qt16 = p.q_tok0 + 16 * cb + n16;
+        const bool live16 = qt16 < qlen;
+        const int64_t qo = ((int64_t)qi * p.Lq + (live16 ? qt16 : 0)) * 128;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, qo + 16 * j + 4 * kq + t);
-        qv[j] = live16 ? v : (f32x4)(0.0f);
+        for (int j = 0; j < 8; ++j) {
+          f32x4 v;
+          if (qf32) {
+            v = *(const f32x4*)((const float*)p.Q + qo + 16 * j + 4 * kq);
+          } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, qo + 16 * j + 4 * kq + t);
+          }
+          qv[8 * cb + j] = live16 ? v : (f32x4)(0.0f);
+        }
       }
     } else if constexpr (DT == MAXSIM_F32) {
       float qs = 1.0f;
@@ -563,8 +644,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 
   Reducer red;
   Reducer16 red16;
+  Reducer2x16 red2;
   red.init();
   red16.init();
+  red2.init();
   int buf = 0;
 
   while (nconsumed < nissued) {
@@ -575,7 +658,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     u32x4 a[NRD];
 #pragma unroll
     for (int i = 0; i < NRD; ++i) {
-      if constexpr (QT == 16) {
+      if constexpr (QT != 32) {
         // operand i = (row block b = i >> 3, k group j = i & 7): row 16 b + (lane & 15), chunk 4 j + (lane >> 4)
         const int n16 = lane & 15;
         a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i >> 3) + n16) * ROWB + 16 * ((4 * (i & 7) + (lane >> 4)) ^ n16));
@@ -608,6 +691,31 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
     }
 
+    if constexpr (QT == QT_2X16) {
+      f32x4 acc[2][2] = {{(f32x4)(0.0f), (f32x4)(0.0f)}, {(f32x4)(0.0f), (f32x4)(0.0f)}};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (ABLATE == 1) {
+          asm volatile("" ::"v"(a[j]), "v"(a[8 + j]));
+          continue;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb)
+              acc[b][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, a[8 * b + j])[t], qv[8 * cb + j][t], acc[b][cb], 0, 0, 0);
+      }
+      float sv2[2][8];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) sv2[cb][v] = acc[v >> 2][cb][v & 3];
+      red2.reduce_tile(sv2, C, dl, lane);
+      ++nconsumed;
+      continue;
+    }
     if constexpr (QT == 16) {
       f32x4 acc[2] = {(f32x4)(0.0f), (f32x4)(0.0f)};
 #pragma unroll
@@ -638,6 +746,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
         if (MODE == MODE_DENSE) av *= mv;
         if (ABLATE == 1) {
           asm volatile("" ::"v"(av));
+#ifdef MAXSIM_SLEEP_ABLATE
+          if (i == 0) __builtin_amdgcn_s_sleep(MAXSIM_SLEEP_ABLATE);
+#endif
           continue;
         }
 #pragma unroll
@@ -731,7 +842,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     ++nconsumed;
   }
   float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
-  if constexpr (QT == 16) {
+  if constexpr (QT == QT_2X16) {
+    red2.drain(C, dl, lane);
+    if (lane < red2.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red2.myscore;
+  } else if constexpr (QT == 16) {
     red16.drain(C, dl, lane);
     if (lane < red16.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red16.myscore;
   } else {

@@ -24,13 +24,18 @@ int launch_stream_v(Params& p, hipStream_t st) {
 template <int MODE, int DT>
 int launch_stream(Params& p, hipStream_t st) {
   constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
-  if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {  // <= 16 query tokens: the 16-column f32 MFMA form
+  if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {
+    // fp32 rerank runs on v_mfma_f32_16x16x4_f32: <= 16 query tokens as one 16-column block (half the matrix work),
+    // otherwise as two.  Same flop rate as the 32x32x2 form, but half the accumulator register traffic per flop:
+    // the chip is power-limited on this kernel (1.9 GHz with fetch + f32 MFMA together, 2.35 GHz with either alone),
+    // and the lighter form buys 2-3 % of clock.  MAXSIM_VARIANT=4 forces the 32x32x2 form.
     const int v16 = env_int("MAXSIM_VARIANT", 0);
     if (p.Lq <= 16 && v16 != 4) {  // (Lq <= 16 implies a single query slice)
       if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
       if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
       return launch_stream_v<MODE, DT, 4, NT0, 0, 16>(p, st);
     }
+    if (v16 == 0) return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
   }
   switch (env_int("MAXSIM_VARIANT", 0)) {
     case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)

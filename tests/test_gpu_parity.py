@@ -131,6 +131,36 @@ def test_f32_mfma_is_an_exact_fmaf_chain(ca):
     np.testing.assert_allclose(score_chain_f32(Q, D, ones_q, ones_d, order)[0], out, rtol=0, atol=1e-5)
 
 
+def test_f32_rerank_is_an_exact_fmaf_chain(ca):
+    """The fp32 rerank kernel (v_mfma_f32_16x16x4_f32, two 16-column blocks): bit-equal to a CPU fp32 fmaf chain in
+    the kernel's k-order (instruction (j, t) consumes dims 16 j + 4 g + t, g = 0..3, one after the other), max over
+    the doc's tokens, pairwise-tree sum over the query tokens -- no tolerance; also for <= 16 query tokens."""
+    gen = torch.Generator().manual_seed(31)
+    L, nd = 45, 5
+    D = nrm(gen, nd * L, 128)
+    r = ca.ColbertRanker(parts=[D], parts_doclens=[[L] * nd], dim=128, index_dtype=torch.float32)
+    order = [16 * j + 4 * g + t for j in range(8) for t in range(4) for g in range(4)]
+    Dm = D.view(nd, L, 128).numpy()
+    for Lq in (32, 16, 9):
+        Q = nrm(gen, 1, Lq, 128)
+        Qm = Q.numpy()
+        acc = np.zeros((nd, Lq, L), dtype=np.float32)
+        for k in order:
+            prod = Qm[0, None, :, None, k].astype(np.float64) * Dm[:, None, :, k].astype(np.float64)
+            acc = (prod + acc.astype(np.float64)).astype(np.float32)      # fmaf: one rounding per step
+        mx = acc.max(-1)                                                    # [nd, Lq]
+        width = 32 if Lq > 16 else 16
+        exp = []
+        for d in range(nd):
+            v = np.zeros(width, dtype=np.float32)
+            v[:Lq] = mx[d]                       # dead query-token lanes hold a zero query: similarity 0
+            while len(v) > 1:
+                v = (v[0::2] + v[1::2]).astype(np.float32)
+            exp.append(v[0])
+        out = r.score_candidates(Q, torch.arange(nd)[None]).cpu().numpy()[0]
+        assert out.tobytes() == np.array(exp, dtype=np.float32).tobytes(), Lq
+
+
 # ------------------------------------------------------------------------------------------------------
 # rank_forward / fused ragged rerank: colbert_ranker.py:75-137
 # ------------------------------------------------------------------------------------------------------
