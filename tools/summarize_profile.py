@@ -21,8 +21,8 @@ def short(name):
 
 
 def one(pattern):
-    f = glob.glob(pattern, recursive=True)
-    return f[0] if f else None
+    f = glob.glob(pattern, recursive=True)  # a directory merged over several runs holds one file set per run: newest wins
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def main():
