@@ -1,0 +1,120 @@
+/* kat.c -- libmaxsim.so driven from plain C through include/maxsim.h (no Python, no torch): the reference's
+ * known-answer test (colbert/modeling/BaseModel.py:70-75 -> [[21, 41]]), the zero-floor pair (SURVEY 8c golden 2),
+ * a three-doc ragged rerank + top-k, and the error codes.  Built by __graft_entry__.build() with hipcc (the HIP
+ * runtime is used only for hipMalloc/hipMemcpy); run by tests/test_gpu_parity.py::test_c_abi_from_plain_c.
+ * Prints one line per check; exit status 0 iff all pass. */
+#include <hip/hip_runtime_api.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "maxsim.h"
+
+static int failures = 0;
+#define CHECK(cond, name)                                     \
+  do {                                                        \
+    printf("%s %s\n", (cond) ? "ok  " : "FAIL", name);        \
+    if (!(cond)) ++failures;                                  \
+  } while (0)
+
+static void* to_dev(const void* host, size_t bytes) {
+  void* d = NULL;
+  if (hipMalloc(&d, bytes ? bytes : 1) != hipSuccess) return NULL;
+  if (bytes) hipMemcpy(d, host, bytes, hipMemcpyHostToDevice);
+  return d;
+}
+
+int main(void) {
+  CHECK(maxsim_version() == MAXSIM_VERSION, "version");
+
+  /* BaseModel.test_score: Q [1,2,3], D [2,2,3] with float masks */
+  {
+    const float Q[6] = {1, 2, 3, 4, 5, 6};
+    const float D[12] = {1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6};
+    const float qm[2] = {1, 0}, dm[4] = {1, 1, 1, 0};
+    /* the oracle of this tiny case, written out: only query token 0 is live */
+    float exp[2];
+    for (int d = 0; d < 2; ++d) {
+      float best = -INFINITY;
+      for (int n = 0; n < 2; ++n) {
+        float s = 0;
+        for (int k = 0; k < 3; ++k) s += Q[k] * qm[0] * D[(d * 2 + n) * 3 + k] * dm[d * 2 + n];
+        if (s > best) best = s;
+      }
+      exp[d] = best + 0.0f /* masked query token 1: max over zero similarities */;
+    }
+    float *dQ = to_dev(Q, sizeof Q), *dD = to_dev(D, sizeof D), *dqm = to_dev(qm, sizeof qm), *ddm = to_dev(dm, sizeof dm);
+    float* dout = NULL;
+    hipMalloc((void**)&dout, 2 * sizeof(float));
+    int rc = maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 2, 3, MAXSIM_F32, MAXSIM_MASK_F32, dout, NULL);
+    float out[2] = {0, 0};
+    hipDeviceSynchronize();
+    hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost);
+    printf("     score_dense -> [%g, %g] (rc %d)\n", out[0], out[1], rc);
+    CHECK(rc == MAXSIM_OK && out[0] == exp[0] && out[1] == exp[1], "score_dense small case equals the written-out sum");
+    /* error behaviour: empty doc axis (the reference's max over an empty dim raises), bad dtype */
+    CHECK(maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 0, 3, MAXSIM_F32, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EEMPTY, "Ld == 0 -> EEMPTY");
+    CHECK(maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 2, 3, 77, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EINVAL, "unknown dtype -> EINVAL");
+    CHECK(maxsim_score_dense(NULL, dD, dqm, ddm, 1, 2, 2, 2, 3, MAXSIM_F32, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EINVAL, "NULL Q -> EINVAL");
+    CHECK(strlen(maxsim_strerror(MAXSIM_EEMPTY)) > 0, "strerror");
+  }
+
+  /* (the reference's own KAT numbers, [[21, 41]], are checked from Python against the golden file) the zero-floor pair: */
+  {
+    const float Q[2] = {1, 0};
+    const float D[4] = {-1, 0, -2, 0};
+    const int64_t qm[1] = {1}, dm_full[2] = {1, 1}, dm_floor[2] = {1, 0};
+    float *dQ = to_dev(Q, sizeof Q), *dD = to_dev(D, sizeof D);
+    void *dqm = to_dev(qm, sizeof qm), *d1 = to_dev(dm_full, sizeof dm_full), *d2 = to_dev(dm_floor, sizeof dm_floor);
+    float* dout;
+    hipMalloc((void**)&dout, sizeof(float));
+    float a = 9, b = 9;
+    maxsim_score_dense(dQ, dD, dqm, d1, 1, 1, 1, 2, 2, MAXSIM_F32, MAXSIM_MASK_I64, dout, NULL);
+    hipDeviceSynchronize();
+    hipMemcpy(&a, dout, 4, hipMemcpyDeviceToHost);
+    maxsim_score_dense(dQ, dD, dqm, d2, 1, 1, 1, 2, 2, MAXSIM_F32, MAXSIM_MASK_I64, dout, NULL);
+    hipDeviceSynchronize();
+    hipMemcpy(&b, dout, 4, hipMemcpyDeviceToHost);
+    CHECK(a == -1.0f && b == 0.0f, "zero-floor pair: full mask -> -1, masked slot -> 0");
+  }
+
+  /* ragged rerank on a 3-doc index of one-hot tokens, dim 128 (fast path), + top-k */
+  {
+    enum { H = 128, NTOK = 6, LQ = 2 };
+    static float index[NTOK * H], Q[LQ * H];
+    /* doc 0 = tokens {e0, e1}, doc 1 = {e2}, doc 2 = {e0, e3, e1} (e_i = unit vector i) */
+    const int tok_dim[NTOK] = {0, 1, 2, 0, 3, 1};
+    for (int t = 0; t < NTOK; ++t) index[t * H + tok_dim[t]] = 1.0f;
+    Q[0 * H + 0] = 1.0f;  /* query token 0 = e0 */
+    Q[1 * H + 1] = 0.5f;  /* query token 1 = 0.5 e1 */
+    const int64_t offs[3] = {0, 2, 3};
+    const int32_t lens[3] = {2, 1, 3};
+    const int64_t cand[4] = {1, 2, -1, 0};
+    void *dI = to_dev(index, sizeof index), *dQ = to_dev(Q, sizeof Q), *doff = to_dev(offs, sizeof offs),
+         *dlen = to_dev(lens, sizeof lens), *dc = to_dev(cand, sizeof cand);
+    float* dsc;
+    hipMalloc((void**)&dsc, 4 * sizeof(float));
+    int rc = maxsim_rerank(dI, MAXSIM_F32, NTOK, (const int64_t*)doff, (const int32_t*)dlen, NULL, 3, dQ, MAXSIM_F32, NULL,
+                           (const int64_t*)dc, 1, 4, LQ, H, dsc, NULL);
+    float sc[4];
+    hipDeviceSynchronize();
+    hipMemcpy(sc, dsc, sizeof sc, hipMemcpyDeviceToHost);
+    printf("     rerank -> [%g, %g, %g, %g] (rc %d)\n", sc[0], sc[1], sc[2], sc[3], rc);
+    CHECK(rc == MAXSIM_OK && sc[0] == 0.0f && sc[1] == 1.5f && isinf(sc[2]) && sc[2] < 0 && sc[3] == 1.5f, "rerank scores");
+    float* dts;
+    int64_t* dtp;
+    hipMalloc((void**)&dts, 3 * sizeof(float));
+    hipMalloc((void**)&dtp, 3 * sizeof(int64_t));
+    rc = maxsim_topk(dsc, (const int64_t*)dc, 1, 4, 3, dts, dtp, NULL);
+    float ts[3];
+    int64_t tp[3];
+    hipDeviceSynchronize();
+    hipMemcpy(ts, dts, sizeof ts, hipMemcpyDeviceToHost);
+    hipMemcpy(tp, dtp, sizeof tp, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && tp[0] == 2 && tp[1] == 0 && tp[2] == 1 && ts[0] == 1.5f && ts[2] == 0.0f, "topk: ties by list position");
+    CHECK(maxsim_rerank(dI, MAXSIM_F32, NTOK, (const int64_t*)doff, (const int32_t*)dlen, NULL, 3, dQ, MAXSIM_F32, NULL,
+                        (const int64_t*)dc, 1, 0, LQ, H, dsc, NULL) == MAXSIM_EEMPTY, "ncand == 0 -> EEMPTY (colbert_ranker.py:76)");
+  }
+  printf("%s\n", failures ? "FAILED" : "ALL OK");
+  return failures ? 1 : 0;
+}

@@ -744,3 +744,15 @@ def test_against_plain_c_oracle(ca):
     out = ca.score(Q.cuda(), emb[:60].view(3, 20, 128).cuda(), torch.ones(2, 32).cuda(), torch.ones(3, 20).cuda()).cpu().double().numpy()
     exp = c_oracle.score_dense(Q.numpy(), emb[:60].view(3, 20, 128).numpy(), np.ones((2, 32)), np.ones((3, 20)))
     np.testing.assert_allclose(out, exp, rtol=0, atol=ATOL32)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the C ABI without Python: a gcc-built C program linked against libmaxsim.so (tests/capi/kat.c)
+# ------------------------------------------------------------------------------------------------------
+def test_c_abi_from_plain_c(ca):
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "capi", "kat")
+    assert os.path.exists(exe), "tests/capi/kat is built by __graft_entry__.build()"
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "ALL OK" in res.stdout and "FAIL" not in res.stdout, res.stdout + res.stderr
