@@ -139,11 +139,12 @@ struct TileMap {
 
 // Lays the next 32 stream rows onto the tile's row slots.  Slots past the stream end repeat the last real row (a
 // duplicate cannot change a max).
+template <int ROWS = 32>
 __device__ __forceinline__ TileMap fill_tile(Cursor& F, const DocLanes& dl, int r) {
-  int filled = 0, nseg = 0, split = 32;
+  int filled = 0, nseg = 0, split = ROWS;
   uint32_t last = 0, myrow = 0, base0 = 0, base1 = 0;
-  while (filled < 32 && F.valid) {
-    const int take = uni(min(32 - filled, max(F.len - F.pos, 0)));  // 0: empty doc / padding slot, just skipped
+  while (filled < ROWS && F.valid) {
+    const int take = uni(min(ROWS - filled, max(F.len - F.pos, 0)));  // 0: empty doc / padding slot, just skipped
     const uint32_t base = F.row0 + (uint32_t)F.pos - (uint32_t)filled;  // slot r -> row base + r
     base0 = (take > 0 && nseg == 0) ? base : base0;
     base1 = (take > 0 && nseg == 1) ? base : base1;
@@ -161,7 +162,7 @@ __device__ __forceinline__ TileMap fill_tile(Cursor& F, const DocLanes& dl, int 
   t.base0 = base0;
   t.base1 = base1;
   t.split = split;
-  t.kind = filled == 0 ? 0 : ((filled == 32 && nseg == 1) ? 1 : ((filled == 32 && nseg == 2) ? 2 : 3));
+  t.kind = filled == 0 ? 0 : ((filled == ROWS && nseg == 1) ? 1 : ((filled == ROWS && nseg == 2) ? 2 : 3));
   return t;
 }
 
@@ -852,6 +853,188 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     red.drain(C, dl, lane);
     if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 rerank on HALF tiles: the stream is cut into 16-row tiles (8 KiB, one row block of v_mfma_f32_16x16x4_f32), the
+// wave's ring holds two of them.  While one half tile is being contracted the other is in flight, and the gap between
+// "tile arrived" and "next fetch issued" (operand reads, row map, address math) never leaves the wave with nothing in
+// flight -- with one 16 KiB tile per wave that gap costs ~10 % of the fetch rate.
+template <int NCB>
+struct ReducerH {
+  float rmax[NCB], myscore;
+  int jdoc;
+  __device__ __forceinline__ void init() {
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) rmax[cb] = NEG_INF;
+    myscore = 0.0f;
+    jdoc = 0;
+  }
+  __device__ __forceinline__ void finish_doc(const Cursor& C, int lane) {
+    float sc;
+    if (C.kind == 0) {
+      // row quarters g, g + 2 (lane halves); with two column blocks the swap also parks block 0 in the lower half
+      // and block 1 in the upper half
+      const uint32_t x0 = __float_as_uint(rmax[0]), x1 = __float_as_uint(rmax[NCB - 1]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(x0, x1, false, false);
+      float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+      const uint32_t xb = __float_as_uint(v);
+      const auto s16 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);  // quarters g, g + 1
+      v = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+      if (C.floor0) v = fmaxf(v, 0.0f);
+      v += dpp_f32<0xB1>(v);
+      v += dpp_f32<0x4E>(v);
+      v += dpp_f32<0x141>(v);
+      v += dpp_f32<0x140>(v);  // 16-lane row sums: row 0 = query tokens 0..15, row 2 = tokens 16..31
+      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0));
+      if (NCB == 2) sc += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    } else {
+      sc = C.kind == 1 ? 0.0f : NEG_INF;
+    }
+    myscore = (lane == jdoc) ? sc : myscore;
+    ++jdoc;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) rmax[cb] = NEG_INF;
+  }
+  // sv[cb][v] = similarity of query token 16 cb + (lane & 15) with tile row 4 (lane >> 4) + v
+  __device__ __forceinline__ void reduce_tile(const float (&sv)[NCB][4], Cursor& C, const DocLanes& dl, int lane) {
+    const int g4 = 4 * (lane >> 4);
+    int filled = 0;
+    while (filled < 16 && C.valid) {
+      const int take = uni(min(16 - filled, max(C.len - C.pos, 0)));
+      if (take == 16) {
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          rmax[cb] = fmaxf(rmax[cb], fmaxf(fmaxf(sv[cb][0], sv[cb][1]), fmaxf(sv[cb][2], sv[cb][3])));
+      } else if (take > 0) {
+        const uint32_t lo = (uint32_t)(filled - g4), n_in = (uint32_t)take;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const bool in = ((uint32_t)v - lo) < n_in;
+#pragma unroll
+          for (int cb = 0; cb < NCB; ++cb) rmax[cb] = fmaxf(rmax[cb], in ? sv[cb][v] : NEG_INF);
+        }
+      }
+      filled += take;
+      C.pos += take;
+      if (C.pos >= C.len) {
+        finish_doc(C, lane);
+        C.next_doc(dl);
+      }
+    }
+  }
+  __device__ __forceinline__ void drain(Cursor& C, const DocLanes& dl, int lane) {
+    while (C.valid) {
+      finish_doc(C, lane);
+      C.next_doc(dl);
+    }
+  }
+};
+
+template <int WAVES, int NCB, int NT = 2, int ABLATE = 0>  // NCB 16-column query blocks: 1 (Lq <= 16) or 2 (Lq <= 32)
+__global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KARGS_TO_PARAMS;
+  constexpr int ROWB = 512, HT = 16 * ROWB, NDMA = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  const int qi = blockIdx.x / p.nchunk;
+  const int chunk = blockIdx.x - qi * p.nchunk;
+  const int dpwv = p.dpw / WAVES;
+  const int c_begin = chunk * p.dpw + wave * dpwv;
+  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  const DocLanes dl = load_doc_lanes<MODE_RERANK>(p, qi, c_begin, ndoc, lane);
+  char* const wlds = lds + wave * (NT * HT);
+  const int n16 = lane & 15, kq = lane >> 4;
+  const char* const tok = (const char*)p.index;
+
+  Cursor F, C;
+  F.init(dl, ndoc);
+  C = F;
+  int nissued = 0, nconsumed = 0;
+  bool prev_issued = false;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const TileMap t = fill_tile<16>(F, dl, n16);
+    if (t.kind != 0) {
+      if (ABLATE != 2) issue_rows<NDMA, 2, 32>(tok, (uint32_t)ROWB, 0u, wlds + j * HT, t, lane);
+      ++nissued;
+    }
+    prev_issued = t.kind != 0;
+  }
+
+  // lane (n, kq) holds Q[16 cb + n][16 j + 4 kq + t] in qv[8 cb + j][t]
+  f32x4 qv[8 * NCB];
+  {
+    int qlen = p.Lq;
+    if (p.q_len) qlen = min(qlen, p.q_len[qi]);
+    const bool qf32 = p.q_dtype == MAXSIM_F32;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int qt = p.q_tok0 + 16 * cb + n16;
+      const bool live = qt < qlen;
+      const int64_t qo = ((int64_t)qi * p.Lq + (live ? qt : 0)) * 128;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 v;
+        if (qf32) {
+          v = *(const f32x4*)((const float*)p.Q + qo + 16 * j + 4 * kq);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, qo + 16 * j + 4 * kq + t);
+        }
+        qv[8 * cb + j] = live ? v : (f32x4)(0.0f);
+      }
+    }
+  }
+
+  ReducerH<NCB> red;
+  red.init();
+  int buf = 0;
+  while (nconsumed < nissued) {
+    __builtin_amdgcn_s_setprio(0);
+    if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
+    u32x4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = *(const u32x4*)(wlds + buf * HT + n16 * ROWB + 16 * ((4 * j + kq) ^ n16));
+    wait_lgkmcnt0();
+    {
+      const TileMap t = fill_tile<16>(F, dl, n16);
+      if (t.kind != 0) {
+        if (ABLATE != 2) issue_rows<NDMA, 2, 32>(tok, (uint32_t)ROWB, 0u, wlds + buf * HT, t, lane);
+        ++nissued;
+      }
+      prev_issued = t.kind != 0;
+    }
+    buf = (buf + 1 == NT) ? 0 : buf + 1;
+    __builtin_amdgcn_s_setprio(3);
+
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4)(0.0f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ABLATE == 1) {
+        asm volatile("" ::"v"(a[j]));
+        continue;
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, a[j])[t], qv[8 * cb + j][t], acc[cb], 0, 0, 0);
+    }
+    float sv[NCB][4];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+      for (int v = 0; v < 4; ++v) sv[cb][v] = acc[cb][v];
+    red.reduce_tile(sv, C, dl, lane);
+    ++nconsumed;
+  }
+  red.drain(C, dl, lane);
+  float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
+  if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
 }
 
 }  // namespace maxsim

@@ -19,6 +19,20 @@ int launch_stream_v(Params& p, hipStream_t st) {
   return check_launch();
 }
 
+template <int WAVES, int NCB, int NT>
+int launch_stream_f32h(Params& p, hipStream_t st) {
+  int dpwv = env_int("MAXSIM_DPW", 0);
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
+  p.dpw = dpwv * WAVES;
+  p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+  const int ldsb = WAVES * NT * 8192;
+  auto kern = k_maxsim_stream_f32h<WAVES, NCB, NT>;
+  int rc = allow_lds(kern, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  return check_launch();
+}
+
 // Per-wave LDS ring: fp32 1 x 16 KiB tile, 16-bit 2 x 8 KiB tiles; 4 waves per workgroup = 64 KiB, two
 // workgroups per CU.  MAXSIM_VARIANT is a diagnostic knob (DESIGN.md "Tuning knobs"): 1/2 = ablation builds.
 template <int MODE, int DT>
@@ -30,6 +44,12 @@ int launch_stream(Params& p, hipStream_t st) {
     // the chip is power-limited on this kernel (1.9 GHz with fetch + f32 MFMA together, 2.35 GHz with either alone),
     // and the lighter form buys 2-3 % of clock.  MAXSIM_VARIANT=4 forces the 32x32x2 form.
     const int v16 = env_int("MAXSIM_VARIANT", 0);
+    // short docs (the 8-token multi-view config): 16-row half tiles, two per wave in the ring -- the first rows of a
+    // short stream arrive sooner and tiles straddle fewer docs: +5-7 % at 8-16 tokens per doc, -2 % from 32 up.
+    // MAXSIM_VARIANT=6 forces this kernel, 8 disables it.
+    const bool short_docs = p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs;
+    if (v16 == 6 || (short_docs && v16 == 0))
+      return p.Lq <= 16 ? launch_stream_f32h<4, 1, 2>(p, st) : launch_stream_f32h<4, 2, 2>(p, st);
     if (p.Lq <= 16 && v16 != 4) {  // (Lq <= 16 implies a single query slice)
       if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
       if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
