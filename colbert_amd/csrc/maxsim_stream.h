@@ -171,7 +171,11 @@ __device__ __forceinline__ TileMap fill_tile(Cursor& F, const DocLanes& dl, int 
 // block inside the row.  Chunk position p of slot m receives source chunk p ^ (m & 15).
 // PART: the row's last 128-dim block may be partial (h not a multiple of 128): chunks past the row end are redirected
 // to the row's first chunk (valid, finite data; the query image is zero there, so they contribute exactly 0).
-template <int NDMA, int RPD, int LPR, bool PART = false>
+// CPOL: cache-policy bits of the loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1).  Rerank streams every doc once per
+// (query, candidate) -- nothing to keep in L2 / Infinity Cache -- and is power-capped, so it loads non-temporal
+// (CPOL_STREAM: 2 % faster on C2); the all-pairs kernels re-read D from cache and keep the default policy.
+constexpr int CPOL_STREAM = 2;
+template <int NDMA, int RPD, int LPR, bool PART = false, int CPOL = 0>
 __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, uint32_t blk, char* l,
                                            const TileMap& t, int lane) {
   // (the lane constants are made opaque so that hipcc recomputes the 2-3 VALU ops per instruction instead of keeping
@@ -186,7 +190,7 @@ __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, u
       uint32_t inrow = 16u * (uint32_t)(dch ^ (slot & 15));
       if (PART) inrow = (blk + inrow < rowbytes) ? blk + inrow : 0u;  // past the row end -> byte 0 of the row
       const uint32_t off = (uint32_t)slot * rowbytes + inrow;
-      __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(base + off), LPTR(l + i * 1024), 16, 0, CPOL);
     }
   } else if (t.kind == 2) {  // the end of one doc and the start of the next: two uniform bases, selected per lane
 #pragma unroll
@@ -196,7 +200,7 @@ __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, u
       uint32_t inrow = blk + 16u * (uint32_t)(dch ^ (slot & 15));
       if (PART && inrow >= rowbytes) inrow = 0u;
       const char* g = tok + (uint64_t)row * rowbytes + inrow;
-      __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, CPOL);
     }
   } else {  // many short docs (or the stream's padded last tile): each slot's row comes from the lane that owns it
     uint32_t rows[NDMA];
@@ -208,7 +212,7 @@ __device__ __forceinline__ void issue_rows(const char* tok, uint32_t rowbytes, u
       uint32_t inrow = blk + 16u * (uint32_t)(dch ^ (slot & 15));
       if (PART && inrow >= rowbytes) inrow = 0u;
       const char* g = tok + (uint64_t)rows[i] * rowbytes + inrow;
-      __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(g), LPTR(l + i * 1024), 16, 0, CPOL);
     }
   }
 }
@@ -527,7 +531,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 
   auto issue_tile = [&](int buf, const TileMap& t) __attribute__((always_inline)) {
     if (ABLATE == 2) return;
-    issue_rows<NDMA, RPD, LPR>(tok, (uint32_t)ROWB, 0u, wlds + buf * TILE, t, lane);
+    issue_rows<NDMA, RPD, LPR, false, MODE == MODE_RERANK ? CPOL_STREAM : 0>(tok, (uint32_t)ROWB, 0u, wlds + buf * TILE, t, lane);
   };
 
   // ---- prologue: up to NT tiles in flight (issued BEFORE the query tile is loaded: its latency overlaps the
@@ -957,7 +961,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
   for (int j = 0; j < NT; ++j) {
     const TileMap t = fill_tile<16>(F, dl, n16);
     if (t.kind != 0) {
-      if (ABLATE != 2) issue_rows<NDMA, 2, 32>(tok, (uint32_t)ROWB, 0u, wlds + j * HT, t, lane);
+      if (ABLATE != 2) issue_rows<NDMA, 2, 32, false, CPOL_STREAM>(tok, (uint32_t)ROWB, 0u, wlds + j * HT, t, lane);
       ++nissued;
     }
     prev_issued = t.kind != 0;
@@ -1001,7 +1005,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
     {
       const TileMap t = fill_tile<16>(F, dl, n16);
       if (t.kind != 0) {
-        if (ABLATE != 2) issue_rows<NDMA, 2, 32>(tok, (uint32_t)ROWB, 0u, wlds + buf * HT, t, lane);
+        if (ABLATE != 2) issue_rows<NDMA, 2, 32, false, CPOL_STREAM>(tok, (uint32_t)ROWB, 0u, wlds + buf * HT, t, lane);
         ++nissued;
       }
       prev_issued = t.kind != 0;

@@ -176,7 +176,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   auto fetch_next = [&](int buf) __attribute__((always_inline)) -> bool {
     if (fkb == 0) ft = fill_tile(F, dl, r);
     if (ft.kind == 0) return false;
-    issue_rows<NDMA, RPD, LPR, PART>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
+    issue_rows<NDMA, RPD, LPR, PART, MODE == MODE_RERANK ? CPOL_STREAM : 0>(tok, rowbytes, (uint32_t)fkb * BLKB, wlds + buf * SUB, ft, lane);
     fkb = (fkb + 1 == KB) ? 0 : fkb + 1;
     return true;
   };
