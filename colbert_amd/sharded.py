@@ -28,17 +28,21 @@ def localize(cand_global, lo, hi):
 
 
 def all_gather_topk(top_s, top_p, world, group=None):
-    """The path's ONE exchange step: every rank's [nq, k] scores and global pids -> [world, nq, k] on every rank."""
+    """The path's ONE exchange step: every rank's [nq, k] scores and global pids -> [world, nq, k] on every rank.
+    Scores travel as their bit patterns next to the pids in one int64 payload, so it is a single collective."""
     nq, k = top_s.shape
     dev = top_s.device
+    payload = torch.empty(nq, 2 * k, dtype=torch.int64, device=dev)
+    payload[:, :k] = top_p
+    payload[:, k:] = top_s.contiguous().view(torch.int32)
     if dev.type == "cuda" and dist.get_backend(group) == "gloo":
         # rehearsal on a one-GPU box (RCCL refuses two ranks on one device): stage through the host
-        top_s, top_p = top_s.cpu(), top_p.cpu()
-    gs = torch.empty(world * nq, k, dtype=top_s.dtype, device=top_s.device)
-    gp = torch.empty(world * nq, k, dtype=top_p.dtype, device=top_p.device)
-    dist.all_gather_into_tensor(gs, top_s.contiguous(), group=group)
-    dist.all_gather_into_tensor(gp, top_p.contiguous(), group=group)
-    return gs.view(world, nq, k).to(dev), gp.view(world, nq, k).to(dev)
+        payload = payload.cpu()
+    g = torch.empty(world * nq, 2 * k, dtype=torch.int64, device=payload.device)
+    dist.all_gather_into_tensor(g, payload, group=group)
+    g = g.view(world, nq, 2 * k).to(dev)
+    gs = g[..., k:].to(torch.int32).view(torch.float32)
+    return gs, g[..., :k]
 
 
 def merge_gathered(all_scores, all_pids, k, topk_fn):
