@@ -164,6 +164,7 @@ def main():
     ranker = colbert_amd.ColbertRanker.from_device_tensor(idx, doclens, fp32_mode=args.fp32_mode)
     lo, hi = rank * ndocs, (rank + 1) * ndocs
     sharded = ShardedRanker(ranker, lo, hi)
+    sharded.force_exchange = args.force_dist
 
     nq = (args.nq or NQ) * world
     per = args.ncand or NCAND // world
@@ -185,20 +186,31 @@ def main():
         scores = ranker.score_candidates(Q, cand_local)
         ev[i][1].record()
         top_p, top_s = ranker.topk(scores, cand_global, TOPK if per >= TOPK else per)
-        if use_dist:
-            from colbert_amd.sharded import all_gather_topk, merge_gathered
-            gs, gp = all_gather_topk(top_s, top_p, world)
-            top_p, top_s = merge_gathered(gs, gp, TOPK, ranker.topk)
-        return top_p, top_s
+        if not use_dist:
+            return top_p, top_s
+        # the ONE exchange step (all_gather over xGMI) + the per-query merge run on the side stream: batch i's exchange
+        # overlaps batch i+1's rerank kernel; every batch is complete before the timed region ends (result() + sync)
+        h = sharded.exchange_async(top_p, top_s, TOPK)
+        if os.environ.get("MAXSIM_BENCH_NO_PIPELINE"):   # diagnostic: resolve the exchange before the next batch is issued
+            h.result()
+        return h
+
+    def finish(h):
+        return h.result() if use_dist else h
 
     for i in range(args.warmup):
-        step(i)
+        finish(step(i))
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    pending = None
     for i in range(args.warmup, total):
-        out = step(i)
+        h = step(i)
+        if pending is not None:
+            out = finish(pending)
+        pending = h
+    out = finish(pending)
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()

@@ -60,6 +60,7 @@ class ShardedRanker:
         self.group = group
         self.score_fn = score_fn if score_fn is not None else local_ranker.score_candidates
         self.topk_fn = topk_fn if topk_fn is not None else local_ranker.topk
+        self.force_exchange = False   # diagnostic: run the exchange + merge even at world size 1 (bench.py --force-dist)
 
     def local_topk(self, Q, cand_global, depth, q_len=None, compact=True):
         cand_local, inr = localize(cand_global, self.lo, self.hi)
@@ -78,12 +79,60 @@ class ShardedRanker:
         gp = gp.to(scores.device)
         return self.topk_fn(scores, gp, k)          # (pids [nq,k] global, scores [nq,k]); padding slots = (-1, -inf)
 
+    def _world(self):
+        if not (dist.is_available() and dist.is_initialized()):
+            return 1
+        return dist.get_world_size(self.group)
+
     def rerank_batch(self, Q, cand_global, depth=10, q_len=None):
         """Every rank passes the same Q [nq,Lq,h] and global candidate lists [nq,ncand]; returns the global
         top-``depth`` (pids, scores) on every rank."""
         top_p, top_s = self.local_topk(Q, cand_global, depth, q_len)
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        world = self._world()
+        if world == 1:
             return top_p, top_s
-        world = dist.get_world_size(self.group)
         gs, gp = all_gather_topk(top_s, top_p, world, self.group)
         return merge_gathered(gs, gp, int(depth), self.topk_fn)
+
+    def exchange_async(self, top_p, top_s, depth):
+        """The exchange + merge of one batch on the ranker's side stream, so that the NEXT batch's rerank kernel (on the
+        caller's stream) runs while this batch's all_gather crosses xGMI.  Returns a handle; ``handle.result()`` makes the
+        caller's stream wait for the merge and returns (pids, scores).  Collectives are issued in call order on every
+        rank, so handles must be created in the same order everywhere."""
+        return _Exchange(self, top_p, top_s, int(depth))
+
+
+class _Exchange:
+    def __init__(self, sr, top_p, top_s, depth):
+        self.out = (top_p, top_s)
+        self.done = None
+        world = sr._world()
+        if world == 1 and not (sr.force_exchange and dist.is_initialized()):
+            return
+        if top_s.device.type != "cuda":        # CPU ranks (gloo tests): synchronous
+            gs, gp = all_gather_topk(top_s, top_p, world, sr.group)
+            self.out = merge_gathered(gs, gp, depth, sr.topk_fn)
+            return
+        dev = top_s.device
+        if getattr(sr, "_side", None) is None:
+            sr._side = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        self._inputs = (top_p, top_s)          # kept alive until result(): they were allocated on the caller's stream
+        with torch.cuda.stream(sr._side):
+            sr._side.wait_event(ready)
+            gs, gp = all_gather_topk(top_s, top_p, world, sr.group)
+            self.out = merge_gathered(gs, gp, depth, sr.topk_fn)
+            self.done = torch.cuda.Event()
+            self.done.record(sr._side)
+
+    def result(self):
+        if self.done is not None:
+            main = torch.cuda.current_stream(self.out[0].device)
+            main.wait_event(self.done)
+            for t in self.out:
+                t.record_stream(main)          # allocated on the side stream, consumed on the caller's
+            self.done = None
+            self._inputs = None
+        return self.out

@@ -75,6 +75,13 @@ def _worker(rank, world, port, ret):
             exp = torch.maximum(exp, sc)
         ep, es = cpu_topk(exp, cand, 5)
         ok = torch.equal(top_s, es) and torch.equal(top_p, ep)
+        # the pipelined form bench.py uses: local top-k, then the exchange as a handle (synchronous on CPU ranks);
+        # two batches in flight, resolved in issue order
+        h1 = sh.exchange_async(*sh.local_topk(Q, cand, 5), 5)
+        h2 = sh.exchange_async(*sh.local_topk(Q, cand.flip(1), 5), 5)
+        p1, s1 = h1.result()
+        p2, s2 = h2.result()
+        ok = ok and torch.equal(s1, es) and torch.equal(p1, ep) and torch.equal(s2, es)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
