@@ -96,7 +96,9 @@ static int score_dense_impl(const void* Q, const void* D, const void* q_mask, co
   p.argmax = argmax;
   p.q_mask = q_mask; p.d_mask = d_mask; p.mask_dtype = mask_dtype;
   p.Ld = Ld;
-  const bool stream_ok = (Lq <= 32 || (!argmax && Lq <= MAX_LQ_SLICED)) && p.n_tokens <= 0xffffffffLL;
+  // the streaming kernels move 16-byte pieces: operands that are not 16-byte aligned take the generic kernel
+  const bool aligned = (((uintptr_t)Q | (uintptr_t)D) & 15) == 0;
+  const bool stream_ok = aligned && (Lq <= 32 || (!argmax && Lq <= MAX_LQ_SLICED)) && p.n_tokens <= 0xffffffffLL;
   if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128)
     return for_query_slices(p, [&] { return launch_stream_dense_f32(p, st); });
   const int esz = dtype == MAXSIM_F32 ? 4 : 2;
@@ -218,7 +220,8 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
   p.nq = nq; p.ncand = ncand; p.Lq = Lq; p.h = h;
   p.scores = scores;
   p.mask_dtype = MAXSIM_MASK_NONE;
-  const bool stream_ok = Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
+  const bool aligned = (((uintptr_t)Q | (uintptr_t)index) & 15) == 0;  // the streaming kernels move 16-byte pieces
+  const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
   if (h == 128 && stream_ok) {
     return for_query_slices(p, [&] { return launch_stream_rerank(p, index_dtype, st); });
   }

@@ -20,7 +20,8 @@
  *     nothing and keeps no state between calls; it is re-entrant per stream;
  *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all work is asynchronous on it;
  *   - return value: MAXSIM_OK (0) or a negative MAXSIM_E* code; no exceptions cross the ABI;
- *   - all tensors are dense row-major.
+ *   - all tensors are dense row-major; any alignment is accepted (token matrices and queries that are not 16-byte
+ *     aligned are scored by the generic kernel instead of the streaming kernels).
  */
 #ifndef MAXSIM_H
 #define MAXSIM_H

@@ -315,6 +315,37 @@ def test_rerank_edge_cases(ca):
     assert sc[0, 3] == sc[0, 4]
 
 
+def test_misaligned_operands_take_the_generic_path(ca):
+    """Device pointers that are not 16-byte aligned (a C caller's sub-buffer; here: views at a 4-byte offset) must
+    not reach the 16-byte LDS-DMA kernels: same scores as the aligned call, to tolerance."""
+    gen = torch.Generator().manual_seed(15)
+    doclens = [7, 180, 33, 1, 64]
+    ntok = sum(doclens)
+    emb, Q = nrm(gen, ntok, 128), nrm(gen, 2, 32, 128)
+    cand = torch.tensor([[4, 0, 1, 2, 3], [1, 1, 3, -1, 0]])
+    r0 = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=128, index_dtype=torch.float32)
+    base = r0.score_candidates(Q, cand).cpu()
+    buf = torch.empty(ntok * 128 + 1, device="cuda")
+    buf[1:] = emb.flatten().cuda()
+    idx_mis = buf[1:].view(ntok, 128)
+    assert idx_mis.data_ptr() % 16 == 4 and idx_mis.is_contiguous()
+    r1 = ca.ColbertRanker.from_device_tensor(idx_mis, doclens)
+    qb = torch.empty(2 * 32 * 128 + 1, device="cuda")
+    qb[1:] = Q.flatten().cuda()
+    Q_mis = qb[1:].view(2, 32, 128)
+    for rr, qq in ((r1, Q.cuda()), (r0, Q_mis), (r1, Q_mis)):
+        got = rr.score_candidates(qq, cand).cpu()
+        fin = torch.isfinite(base)
+        assert torch.equal(fin, torch.isfinite(got))
+        assert float((got[fin] - base[fin]).abs().max()) <= ATOL32
+    D = nrm(gen, 3, 20, 128)
+    db = torch.empty(D.numel() + 1, device="cuda")
+    db[1:] = D.flatten().cuda()
+    ones_q, ones_d = torch.ones(2, 32).cuda(), torch.ones(3, 20).cuda()
+    torch.testing.assert_close(ca.score(Q_mis, db[1:].view(3, 20, 128), ones_q, ones_d),
+                               ca.score(Q.cuda(), D.cuda(), ones_q, ones_d), rtol=0, atol=ATOL32)
+
+
 # ------------------------------------------------------------------------------------------------------
 # top-k: colbert_ranker.py:128-130
 # ------------------------------------------------------------------------------------------------------
