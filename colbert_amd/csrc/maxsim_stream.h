@@ -3,18 +3,20 @@
 // One wave64 = one independent TOKEN STREAM: the tokens of the wave's candidate docs laid end to end.  The stream
 // is cut into 32-row tiles that may straddle document boundaries ("packed tiles": no MFMA work is spent on
 // padding except in the wave's very last tile).  Per tile:
-//   fetch    NDMA LDS-DMA instructions (global_load_lds_dwordx4, 1 KiB each = whole token rows; a tile that lies
+//   fetch    NDMA LDS-DMA instructions (global_load_lds_dwordx4, non-temporal in rerank mode -- the bytes are read
+//            once and the board is power-capped, so they skip cache allocation; 1 KiB each = whole token rows; a tile that lies
 //            inside one doc is one contiguous burst addressed SGPR-base + lane offset; a tile that crosses docs
 //            takes each row's address from the lane that owns the slot via ds_bpermute) into the wave's private
 //            LDS ring of NT tiles.  Source chunk j of row slot m is stored at chunk position j ^ (m & 15): the
 //            LDS-DMA destination stays linear (it must), the ds_read_b128 operand reads are bank-conflict free.
 //   compute  the whole tile goes to registers (A operands), the NEXT tile's fetch is issued into the freed
 //            buffer, then the contraction runs on MFMA with fp32 accumulation:
-//              fp32 index: v_mfma_f32_32x32x2_f32 -- an exact k-ordered fp32 fmaf chain (bitwise reproducible);
+//              fp32 index: v_mfma_f32_16x16x4_f32 (rerank: the query tokens as one or two 16-column blocks) or
+//                          v_mfma_f32_32x32x2_f32 (dense) -- an exact k-ordered fp32 fmaf chain (bitwise reproducible);
 //              fp16 index: v_mfma_f32_32x32x16_f16, Q = Qhi + 2^-11 Qlo (two accumulators);
 //              bf16 index: v_mfma_f32_32x32x16_bf16, Q = Q0 + Q1 + Q2.
-//            A = doc tokens (rows), B = query tokens (columns): a lane's 16 accumulators are 16 doc tokens of ONE
-//            query token, so max-over-doc-tokens is in-lane + one exchange between the lane halves.
+//            A = doc tokens (rows), B = query tokens (columns): a lane's accumulators are doc tokens of ONE query
+//            token, so max-over-doc-tokens is in-lane + an exchange between the lane groups holding that token.
 //   reduce   per document segment of the tile: (masked) max into the doc's running max; when a doc ends:
 //            halves exchange, 0-floor, DPP pairwise-tree sum over query tokens, score kept in lane (doc ordinal).
 // There is no workgroup barrier: waves pace their own ring with counted s_waitcnt vmcnt.
