@@ -1,5 +1,5 @@
 /* kat.c -- libmaxsim.so driven from plain C through include/maxsim.h (no Python, no torch): the reference's
- * known-answer test (colbert/modeling/BaseModel.py:70-75 -> [[21, 41]]), the zero-floor pair (SURVEY 8c golden 2),
+ * known-answer test (colbert/modeling/BaseModel.py:70-75 -> [[21, 41]]), a masked variant, the zero-floor pair (SURVEY 8c golden 2),
  * a three-doc ragged rerank + top-k, and the error codes.  Built by __graft_entry__.build() with hipcc (the HIP
  * runtime is used only for hipMalloc/hipMemcpy); run by tests/test_gpu_parity.py::test_c_abi_from_plain_c.
  * Prints one line per check; exit status 0 iff all pass. */
@@ -27,22 +27,11 @@ static void* to_dev(const void* host, size_t bytes) {
 int main(void) {
   CHECK(maxsim_version() == MAXSIM_VERSION, "version");
 
-  /* BaseModel.test_score: Q [1,2,3], D [2,2,3] with float masks */
+  /* the reference's known-answer test, BaseModel.test_score (BaseModel.py:70-75): all-ones float masks -> [[21, 41]] */
   {
-    const float Q[6] = {1, 2, 3, 4, 5, 6};
-    const float D[12] = {1, 2, 3, 2, 3, 4, 3, 4, 5, 4, 5, 6};
-    const float qm[2] = {1, 0}, dm[4] = {1, 1, 1, 0};
-    /* the oracle of this tiny case, written out: only query token 0 is live */
-    float exp[2];
-    for (int d = 0; d < 2; ++d) {
-      float best = -INFINITY;
-      for (int n = 0; n < 2; ++n) {
-        float s = 0;
-        for (int k = 0; k < 3; ++k) s += Q[k] * qm[0] * D[(d * 2 + n) * 3 + k] * dm[d * 2 + n];
-        if (s > best) best = s;
-      }
-      exp[d] = best + 0.0f /* masked query token 1: max over zero similarities */;
-    }
+    const float Q[6] = {1, 5, 4, 2, 8, 1};
+    const float D[12] = {0, 0, 0, 1, 1, 1, 3, 2, 1, 1, 1, 3};
+    const float qm[2] = {1, 1}, dm[4] = {1, 1, 1, 1};
     float *dQ = to_dev(Q, sizeof Q), *dD = to_dev(D, sizeof D), *dqm = to_dev(qm, sizeof qm), *ddm = to_dev(dm, sizeof dm);
     float* dout = NULL;
     hipMalloc((void**)&dout, 2 * sizeof(float));
@@ -51,7 +40,15 @@ int main(void) {
     hipDeviceSynchronize();
     hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost);
     printf("     score_dense -> [%g, %g] (rc %d)\n", out[0], out[1], rc);
-    CHECK(rc == MAXSIM_OK && out[0] == exp[0] && out[1] == exp[1], "score_dense small case equals the written-out sum");
+    CHECK(rc == MAXSIM_OK && out[0] == 21.0f && out[1] == 41.0f, "test_score KAT = [[21, 41]]");
+    /* a masked query token contributes 0, a masked doc token similarity 0 (BaseModel.py:41-42) */
+    const float qm2[2] = {1, 0}, dm2[4] = {1, 1, 1, 0};
+    hipMemcpy(dqm, qm2, sizeof qm2, hipMemcpyHostToDevice);
+    hipMemcpy(ddm, dm2, sizeof dm2, hipMemcpyHostToDevice);
+    rc = maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 2, 3, MAXSIM_F32, MAXSIM_MASK_F32, dout, NULL);
+    hipDeviceSynchronize();
+    hipMemcpy(out, dout, sizeof out, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && out[0] == 10.0f && out[1] == 17.0f, "masks: query token 1 and doc 1's second token masked -> [[10, 17]]");
     /* error behaviour: empty doc axis (the reference's max over an empty dim raises), bad dtype */
     CHECK(maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 0, 3, MAXSIM_F32, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EEMPTY, "Ld == 0 -> EEMPTY");
     CHECK(maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 2, 3, 77, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EINVAL, "unknown dtype -> EINVAL");
