@@ -103,8 +103,8 @@ def cpu_baseline(seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--ndocs", type=int, default=0, help="docs per GPU shard (0 = the workload's default)")
     ap.add_argument("--index-dtype", default="", choices=["", "fp32", "fp16", "bf16"])
