@@ -9,6 +9,7 @@ loop of colbert/training/dense_server_client.py:44-48.  ``rank_forward`` keeps t
 asserts and return contract so ``ColbertRetriever.search`` (colbert/indexing/faiss_indexers.py:224-235) can
 call it unchanged.
 """
+import array
 from itertools import accumulate
 
 import torch
@@ -190,12 +191,18 @@ class ColbertRanker:
             # the reference's per-candidate-query branch (:103) takes row [0] of an all-pairs result (:112) --
             # a latent bug that is never exercised (faiss_indexers.py:232-234 always passes one query).
             raise NotImplementedError("rank_forward with one query per candidate is not exercised by the reference")
-        raw_pids = pids if type(pids) is list else pids.tolist()
-        pids_t = torch.tensor(pids) if type(pids) is list else pids
+        if type(pids) is list:
+            n_pids = len(pids)
+            try:        # 1000 python ints: 14 us through array('q') against 50-75 us for torch.tensor(list)
+                pids_t = torch.frombuffer(array.array("q", pids), dtype=torch.int64)
+            except (TypeError, OverflowError):
+                pids_t = torch.tensor(pids)
+        else:
+            pids_t, n_pids = pids, len(pids)
         Qt = Q.to(self.device).permute(0, 2, 1)                               # :78, :111 -> [1, Lq, h]
         cand = pids_t.to(self.device, torch.int64).view(1, -1)
         scores = self.score_candidates(Qt, cand)
-        k = min(int(depth), len(raw_pids))
+        k = min(int(depth), n_pids)
         top_p, top_s = self.topk(scores, cand, k)                             # :128-130
         if output_D_embedding:                                                # :131-136
             return self._output_D(top_p[0], k)
