@@ -141,12 +141,17 @@ class ColbertRanker:
         _lib.check(rc, "maxsim_rerank")
         return scores
 
-    def topk(self, scores, pids, k):
-        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k])."""
+    def topk(self, scores, pids, k, _packed=None):
+        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k]).
+        (``_packed``: a uint8 buffer of nq*k*12 bytes that receives both outputs -- one D2H copy for rank_forward.)"""
         dev = scores.device
         nq, n = scores.shape
-        out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
-        out_p = torch.empty(nq, k, dtype=torch.int64, device=dev)
+        if _packed is None:
+            out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+            out_p = torch.empty(nq, k, dtype=torch.int64, device=dev)
+        else:
+            out_p = _packed[: nq * k * 8].view(torch.int64).view(nq, k)
+            out_s = _packed[nq * k * 8:].view(torch.float32).view(nq, k)
         scores = scores.contiguous()
         pids = None if pids is None else pids.to(device=dev, dtype=torch.int64).contiguous()
         with torch.cuda.device(dev):
@@ -203,10 +208,12 @@ class ColbertRanker:
         cand = pids_t.to(self.device, torch.int64).view(1, -1)
         scores = self.score_candidates(Qt, cand)
         k = min(int(depth), n_pids)
-        top_p, top_s = self.topk(scores, cand, k)                             # :128-130
+        packed = torch.empty(k * 12, dtype=torch.uint8, device=self.device)   # pids and scores leave in ONE copy
+        top_p, top_s = self.topk(scores, cand, k, _packed=packed)             # :128-130
         if output_D_embedding:                                                # :131-136
             return self._output_D(top_p[0], k)
-        return top_p[0].tolist(), top_s[0].tolist()
+        host = packed.cpu()
+        return host[: k * 8].view(torch.int64).tolist(), host[k * 8:].view(torch.float32).tolist()
 
     def _output_D(self, top_pids, k):
         """colbert_ranker.py:131-136: padded D [k, S, h] and mask of the top docs.  The reference's
