@@ -230,13 +230,14 @@ def main():
 
     # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
     # MI355X_MICROARCH.md prescribes; summary committed under profiles/ by tools/summarize_profile.py)
-    traffic = None
+    traffic = mfma_busy = None
     pmc = os.path.join(ROOT, "profiles", f"r01_{args.workload}_{'f32' if args.index_dtype == 'fp32' else args.index_dtype}_pmc.json")
     if world == 1 and ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand or args.ld) and os.path.exists(pmc):
         try:
             for k, v in json.load(open(pmc)).items():
                 if "k_maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
                     traffic = int(v["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] + v.get("hbm_write_bytes_per_launch(WRITE_SIZE*1024)", 0))
+                    mfma_busy = v.get("mfma_util(SQ_VALU_MFMA_BUSY_CYCLES/1024 / (GRBM_GUI_ACTIVE/8))")
         except (OSError, ValueError):
             traffic = None
 
@@ -255,7 +256,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes},
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         # matrix-pipe view of the same launch (PMC pass, profiles/): busy fraction of the MFMA pipe
+                         "mfma_busy_frac": None if mfma_busy is None else round(mfma_busy, 3),
+                         "mfma_tflops": round(2.0 * LQ * H * cand_tokens / (kern_ms * 1e-3) / 1e12, 1)},
         }
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             # the reference's online call: ONE query x 1000 candidates through rank_forward (faiss_indexers.py:234),
