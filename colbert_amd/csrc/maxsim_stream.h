@@ -13,8 +13,8 @@
 //            buffer, then the contraction runs on MFMA with fp32 accumulation:
 //              fp32 index: v_mfma_f32_16x16x4_f32 (rerank: the query tokens as one or two 16-column blocks) or
 //                          v_mfma_f32_32x32x2_f32 (dense) -- an exact k-ordered fp32 fmaf chain (bitwise reproducible);
-//              fp16 index: v_mfma_f32_32x32x16_f16, Q = Qhi + 2^-11 Qlo (two accumulators);
-//              bf16 index: v_mfma_f32_32x32x16_bf16, Q = Q0 + Q1 + Q2.
+//              fp16 index: v_mfma_f32_16x16x32_f16 (rerank) / 32x32x16 (other), Q = Qhi + 2^-11 Qlo (two accumulators);
+//              bf16 index: v_mfma_f32_16x16x32_bf16 (rerank) / 32x32x16, Q = Q0 + Q1 + Q2.
 //            A = doc tokens (rows), B = query tokens (columns): a lane's accumulators are doc tokens of ONE query
 //            token, so max-over-doc-tokens is in-lane + an exchange between the lane groups holding that token.
 //   reduce   per document segment of the tile: (masked) max into the doc's running max; when a doc ends:
@@ -506,7 +506,9 @@ constexpr int QT_2X16 = 48;  // 32 query tokens as two 16-column blocks of v_mfm
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
-  static_assert(QT == 32 || ((QT == 16 || QT == QT_2X16) && DT == MAXSIM_F32 && MODE == MODE_RERANK), "16-column forms: fp32 rerank only");
+  static_assert(QT == 32 || (MODE == MODE_RERANK && ((QT == 16 && DT == MAXSIM_F32) ||
+                                                     (QT == QT_2X16 && DT != F32S))),
+                "16-column forms: rerank only (the fp16-split fast mode keeps the 32x32x16 form: 1 % faster there)");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   using T = StreamTraits<DT>;
@@ -564,7 +566,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     const int64_t qoff = ((int64_t)qi * p.Lq + (live ? qtok : 0)) * 128;
     const float* qrow = (const float*)p.Q + qoff;
     const bool qf32 = p.q_dtype == MAXSIM_F32;  // a 16-bit query is widened element by element (start-up only)
-    if constexpr (QT != 32) {
+    if constexpr (QT != 32 && DT == MAXSIM_F32) {
       // lane (n = lane & 15, kq = lane >> 4) holds Q[16 cb + n][16 j + 4 kq + t] in qv[8 cb + j][t], j = 0..7
       const int n16 = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -604,20 +606,29 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     } else {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
+        // 32-column form: lane (n, hh) takes dims 16 i + 8 hh .. + 7 of token n into qp[.][i];
+        // two 16-column blocks (QT_2X16): lane (n16, kq), i = 4 cb + j: dims 8 (4 j + kq) .. + 7 of token 16 cb + n16
+        bool lv = live;
+        int64_t e0 = qoff + 8 * hh + 16 * i;
+        if constexpr (QT == QT_2X16) {
+          const int tok16 = p.q_tok0 + 16 * (i >> 2) + (lane & 15);
+          lv = tok16 < qlen;
+          e0 = ((int64_t)qi * p.Lq + (lv ? tok16 : 0)) * 128 + 8 * (4 * (i & 3) + (lane >> 4));
+        }
         float q[8];
         if (qf32) {
-          const f32x4 v0 = *(const f32x4*)(qrow + 8 * hh + 16 * i);
-          const f32x4 v1 = *(const f32x4*)(qrow + 8 * hh + 16 * i + 4);
+          const f32x4 v0 = *(const f32x4*)((const float*)p.Q + e0);
+          const f32x4 v1 = *(const f32x4*)((const float*)p.Q + e0 + 4);
 #pragma unroll
           for (int j = 0; j < 4; ++j) { q[j] = v0[j]; q[4 + j] = v1[j]; }
         } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) q[j] = load_q(p.Q, p.q_dtype, qoff + 8 * hh + 16 * i + j);
+          for (int j = 0; j < 8; ++j) q[j] = load_q(p.Q, p.q_dtype, e0 + j);
         }
         uint16_t pc[NP][8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float x = live ? q[j] : 0.0f;
+          const float x = lv ? q[j] : 0.0f;
           if constexpr (DT == F32X) {  // exact truncation split: x = t0 + t1 + t2
             const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
             const float r1 = x - __uint_as_float(u0);
@@ -665,10 +676,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     u32x4 a[NRD];
 #pragma unroll
     for (int i = 0; i < NRD; ++i) {
-      if constexpr (QT != 32) {
-        // operand i = (row block b = i >> 3, k group j = i & 7): row 16 b + (lane & 15), chunk 4 j + (lane >> 4)
+      if constexpr (QT == QT_2X16 && DT == F32X) {
+        // fp32 storage contracted in 16-bit pieces: a lane's k-step operand is 8 consecutive dims = two 16-byte chunks:
+        // operand pair (2 u, 2 u + 1), u = 4 b + j: row 16 b + (lane & 15), chunks 2 (4 j + (lane >> 4)) + {0, 1}
         const int n16 = lane & 15;
-        a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i >> 3) + n16) * ROWB + 16 * ((4 * (i & 7) + (lane >> 4)) ^ n16));
+        const int c = 2 * (4 * ((i >> 1) & 3) + (lane >> 4)) + (i & 1);
+        a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i >> 3) + n16) * ROWB + 16 * (c ^ n16));
+      } else if constexpr (QT != 32) {
+        // operand i = (row block b = i / CPB, k group j = i % CPB): row 16 b + (lane & 15), chunk 4 j + (lane >> 4)
+        constexpr int CPB = NRD / 2;
+        const int n16 = lane & 15;
+        a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i / CPB) + n16) * ROWB + 16 * ((4 * (i % CPB) + (lane >> 4)) ^ n16));
       } else {
         // chunk of the row this lane needs for operand i: 16-bit MFMA k-step = 8 consecutive dims per lane half
         const int c = (DT == F32S || DT == F32X) ? (4 * (i >> 1) + 2 * hh + (i & 1)) : (2 * i + hh);
@@ -698,7 +716,87 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
     }
 
-    if constexpr (QT == QT_2X16) {
+    if constexpr (QT == QT_2X16 && DT != MAXSIM_F32) {
+      // v_mfma_f32_16x16x32_{f16,bf16}: the chip holds a higher clock on this shape than on 32x32x16 at the same
+      // flop rate (MI355X_MICROARCH.md, DVFS give-back item 7), and these kernels run on the board power cap
+      f32x4 acc0[2][2], acc1[2][2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) acc0[b][cb] = acc1[b][cb] = (f32x4)(0.0f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          if constexpr (DT == F32X) {
+            const u32x4 x0 = a[8 * b + 2 * j], x1 = a[8 * b + 2 * j + 1];
+            if (ABLATE == 1) {
+              asm volatile("" ::"v"(x0), "v"(x1));
+              continue;
+            }
+            {
+              u32x4 t0, t1, t2;  // packed bf16 pairs: element w = dims 2w, 2w+1 of this lane's 8
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                const uint32_t xa = w < 2 ? x0[2 * w] : x1[2 * w - 4], xb = w < 2 ? x0[2 * w + 1] : x1[2 * w - 3];
+                const float ra = __uint_as_float(xa) - __uint_as_float(xa & 0xffff0000u);
+                const float rb = __uint_as_float(xb) - __uint_as_float(xb & 0xffff0000u);
+                const uint32_t ua = __float_as_uint(ra), ub = __float_as_uint(rb);
+                const float sa = ra - __uint_as_float(ua & 0xffff0000u);
+                const float sb = rb - __uint_as_float(ub & 0xffff0000u);
+                t0[w] = __builtin_amdgcn_perm(xb, xa, 0x07060302u);  // (hi16(xb) << 16) | hi16(xa)
+                t1[w] = __builtin_amdgcn_perm(ub, ua, 0x07060302u);
+                t2[w] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+              }
+              const bf16x8 d0 = __builtin_bit_cast(bf16x8, t0), d1 = __builtin_bit_cast(bf16x8, t1), d2 = __builtin_bit_cast(bf16x8, t2);
+#pragma unroll
+              for (int cb = 0; cb < 2; ++cb) {  // one accumulator per block: small piece products first within a k-step
+                const bf16x8 q0 = __builtin_bit_cast(bf16x8, qp[0][4 * cb + j]), q1 = __builtin_bit_cast(bf16x8, qp[1][4 * cb + j]),
+                             q2 = __builtin_bit_cast(bf16x8, qp[NP - 1][4 * cb + j]);
+                f32x4 c = acc0[b][cb];
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d2, q0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, q1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, q2, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d1, q0, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, q1, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(d0, q0, c, 0, 0, 0);
+                acc0[b][cb] = c;
+              }
+            }
+          } else {
+            if (ABLATE == 1) {
+              asm volatile("" ::"v"(a[4 * b + j]));
+              continue;
+            }
+#pragma unroll
+            for (int cb = 0; cb < 2; ++cb) {
+              if constexpr (DT == MAXSIM_F16) {
+                const f16x8 av = __builtin_bit_cast(f16x8, a[4 * b + j]);
+                acc0[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, qp[0][4 * cb + j]), acc0[b][cb], 0, 0, 0);
+                acc1[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, qp[1][4 * cb + j]), acc1[b][cb], 0, 0, 0);
+              } else {
+                const bf16x8 av = __builtin_bit_cast(bf16x8, a[4 * b + j]);
+                acc0[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, qp[0][4 * cb + j]), acc0[b][cb], 0, 0, 0);
+                acc1[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, qp[1][4 * cb + j]), acc1[b][cb], 0, 0, 0);
+                acc1[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, qp[NP - 1][4 * cb + j]), acc1[b][cb], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      float sv2[2][8];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+          const float s0 = acc0[v >> 2][cb][v & 3], s1 = acc1[v >> 2][cb][v & 3];
+          sv2[cb][v] = (DT == MAXSIM_F16) ? fmaf(s1, 1.0f / 2048.0f, s0) : (s0 + s1);
+        }
+      red2.reduce_tile(sv2, C, dl, lane);
+      ++nconsumed;
+      continue;
+    }
+    if constexpr (QT == QT_2X16 && DT == MAXSIM_F32) {
       f32x4 acc[2][2] = {{(f32x4)(0.0f), (f32x4)(0.0f)}, {(f32x4)(0.0f), (f32x4)(0.0f)}};
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

@@ -57,6 +57,12 @@ int launch_stream(Params& p, hipStream_t st) {
     }
     if (v16 == 0) return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
   }
+  if constexpr (MODE == MODE_RERANK && DT != MAXSIM_F32 && DT != MAXSIM_F32_FAST) {
+    // 16-bit index and the 3 x bf16 mode of an fp32 index: v_mfma_f32_16x16x32 in two 16-column blocks (+2-3 %; the
+    // fp16-split fast mode measured 1 % slower in this form and keeps 32x32x16) (a higher sustained clock than 32x32x16 on the power
+    // cap); MAXSIM_VARIANT=4 forces the 32x32x16 form
+    if (env_int("MAXSIM_VARIANT", 0) == 0) return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
+  }
   switch (env_int("MAXSIM_VARIANT", 0)) {
     case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)
     case 2: return launch_stream_v<MODE, DT, 4, NT0, 2>(p, st);  // no DMA   (timing only, wrong results)
