@@ -731,6 +731,42 @@ def test_side_stream_and_hipgraph_replay(ca):
     assert torch.equal(gp, e2p) and torch.equal(gs, e2s)
 
 
+def test_concurrent_streams_and_threads(ca):
+    """The library keeps no state between calls: launches racing on several streams, issued from several host threads,
+    return bit-identical results to the serial call (fp32, fp16 and dim-768 kernels, i.e. every LDS-attribute path)."""
+    import threading
+    gen = torch.Generator().manual_seed(99)
+    cfgs = []
+    for h, dt in ((128, torch.float32), (128, torch.float16), (768, torch.bfloat16)):
+        parts, pdl = _random_index(gen, 300, h, 5, 180, dt)
+        r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=h, index_dtype=dt)
+        Q = nrm(gen, 6, 32, h).cuda()
+        cand = torch.stack([torch.randperm(300, generator=gen)[:150] for _ in range(6)]).cuda()
+        cfgs.append((r, Q, cand, r.rerank_batch(Q, cand, depth=20)))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for it in range(12):
+                    r, Q, cand, (ep, es) = cfgs[(tid + it) % len(cfgs)]
+                    p_, s_ = r.rerank_batch(Q, cand, depth=20)
+                    st.synchronize()
+                    if not (torch.equal(p_, ep) and torch.equal(s_, es)):
+                        errors.append((tid, it))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
 def test_sharded_ranker_local_leg_on_gpu(ca):
     """One shard of a doc-sharded index on the GPU (the collective leg is covered by the gloo test): candidates outside
     the shard's pid range are padding, the shard's own are compacted to the front, top-k carries GLOBAL pids."""
