@@ -3,6 +3,7 @@
 loudly if it has not been built."""
 from . import _lib
 from .ranker import ColbertRanker
+from .retriever import retrieve_batch
 from .scoring import MaxSimModel, score
 
-__all__ = ["ColbertRanker", "MaxSimModel", "score", "_lib"]
+__all__ = ["ColbertRanker", "MaxSimModel", "score", "retrieve_batch", "_lib"]

@@ -16,7 +16,15 @@ OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 
 SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk",
            "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
-           "maxsim_score_dense_bwd_workspace")
+           "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_doc_table_bytes",
+           "maxsim_build_doc_table", "maxsim_shard_candidates")
+
+
+class IndexView(ctypes.Structure):
+    """``maxsim_index_view`` (include/maxsim.h)."""
+    _fields_ = [("index", ctypes.c_void_p), ("index_dtype", ctypes.c_int32), ("h", ctypes.c_int32),
+                ("n_tokens", ctypes.c_int64), ("tok_offsets", ctypes.c_void_p), ("doclens", ctypes.c_void_p),
+                ("pad_len", ctypes.c_void_p), ("n_docs", ctypes.c_int64), ("doc_table", ctypes.c_void_p)]
 
 
 class MaxSimError(RuntimeError):
@@ -51,6 +59,17 @@ def _load():
     lib.maxsim_score_dense_bwd.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp, i64, vp]
     lib.maxsim_score_dense_bwd_workspace.restype = i64
     lib.maxsim_score_dense_bwd_workspace.argtypes = [i32, i32, i32, i32]
+    ivp = ctypes.POINTER(IndexView)
+    lib.maxsim_rerank_ex.restype = i32
+    lib.maxsim_rerank_ex.argtypes = [ivp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp]
+    lib.maxsim_rank_forward.restype = i32
+    lib.maxsim_rank_forward.argtypes = [ivp, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp]
+    lib.maxsim_doc_table_bytes.restype = i64
+    lib.maxsim_doc_table_bytes.argtypes = [i64]
+    lib.maxsim_build_doc_table.restype = i32
+    lib.maxsim_build_doc_table.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.maxsim_shard_candidates.restype = i32
+    lib.maxsim_shard_candidates.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
     return lib

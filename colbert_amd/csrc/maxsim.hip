@@ -12,6 +12,7 @@
 #include "maxsim_common.h"
 #include "maxsim_generic.h"
 #include "maxsim_launch.h"
+#include "maxsim_shard.h"
 #include "maxsim_topk.h"
 
 using namespace maxsim;
@@ -193,34 +194,38 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   return check_launch();
 }
 
-int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,
-                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const void* Q, int q_dtype,
-                  const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
-                  float* scores, void* stream) {
+static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, const int32_t* q_len,
+                       const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
+                       hipStream_t st) {
+  const int h = iv.h, index_dtype = iv.index_dtype;
+  const int64_t n_tokens = iv.n_tokens, n_docs = iv.n_docs;
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
   if (index_dtype < MAXSIM_F32 || index_dtype > MAXSIM_F32_BF16X3) return MAXSIM_EINVAL;
   if (q_dtype < MAXSIM_F32 || q_dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
   if (ncand == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
   if (nq == 0) return MAXSIM_OK;
-  if (!scores || !cand_pids || !tok_offsets || !doclens || !Q) return MAXSIM_EINVAL;
-  if (n_tokens > 0 && !index) return MAXSIM_EINVAL;
+  if (!scores || !cand_pids || !Q) return MAXSIM_EINVAL;
+  if (!iv.doc_table && (!iv.tok_offsets || !iv.doclens)) return MAXSIM_EINVAL;
+  if (((uintptr_t)iv.doc_table & 15) != 0) return MAXSIM_EINVAL;
+  if (n_tokens > 0 && !iv.index) return MAXSIM_EINVAL;
   if ((int64_t)nq * ncand > 0x7fffffffLL) return MAXSIM_ERANGE;
-  hipStream_t st = (hipStream_t)stream;
   Params p{};
-  p.index = index;
+  p.index = iv.index;
   p.n_tokens = n_tokens;
-  p.tok_offsets = tok_offsets;
-  p.doclens = doclens;
-  p.pad_len = pad_len;
+  p.tok_offsets = iv.tok_offsets;
+  p.doclens = iv.doclens;
+  p.pad_len = iv.pad_len;
+  p.doc_table = iv.doc_table;
   p.n_docs = n_docs;
   p.Q = Q;
   p.q_dtype = q_dtype;
   p.q_len = q_len;
+  p.q_mask = q_mask;  // rerank mode: uint8 keep-predicate (maxsim_common.h q_token_live)
   p.cand = cand_pids;
   p.nq = nq; p.ncand = ncand; p.Lq = Lq; p.h = h;
   p.scores = scores;
   p.mask_dtype = MAXSIM_MASK_NONE;
-  const bool aligned = (((uintptr_t)Q | (uintptr_t)index) & 15) == 0;  // the streaming kernels move 16-byte pieces
+  const bool aligned = (((uintptr_t)Q | (uintptr_t)iv.index) & 15) == 0;  // the streaming kernels move 16-byte pieces
   const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
   if (h == 128 && stream_ok) {
     return for_query_slices(p, [&] { return launch_stream_rerank(p, index_dtype, st); });
@@ -232,6 +237,52 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
     if (rc != MAXSIM_ERANGE) return rc;
   }
   return launch_generic<MODE_RERANK>(p, index_dtype >= MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype, st);
+}
+
+int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const int64_t* tok_offsets,
+                  const int32_t* doclens, const int32_t* pad_len, int64_t n_docs, const void* Q, int q_dtype,
+                  const int32_t* q_len, const int64_t* cand_pids, int nq, int ncand, int Lq, int h,
+                  float* scores, void* stream) {
+  maxsim_index_view iv{};
+  iv.index = index;
+  iv.index_dtype = index_dtype;
+  iv.h = h;
+  iv.n_tokens = n_tokens;
+  iv.tok_offsets = tok_offsets;
+  iv.doclens = doclens;
+  iv.pad_len = pad_len;
+  iv.n_docs = n_docs;
+  return rerank_impl(iv, Q, q_dtype, q_len, nullptr, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream);
+}
+
+int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
+                     const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
+                     void* stream) {
+  if (!iv) return MAXSIM_EINVAL;
+  return rerank_impl(*iv, Q, q_dtype, q_len, q_mask, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream);
+}
+
+int64_t maxsim_doc_table_bytes(int64_t n_docs) { return n_docs > 0 ? n_docs * 16 : 0; }
+
+int maxsim_build_doc_table(const int64_t* tok_offsets, const int32_t* doclens, const int32_t* pad_len,
+                           int64_t n_docs, void* table, void* stream) {
+  if (n_docs < 0) return MAXSIM_EINVAL;
+  if (n_docs == 0) return MAXSIM_OK;
+  if (!tok_offsets || !doclens || !table || ((uintptr_t)table & 15) != 0) return MAXSIM_EINVAL;
+  if ((n_docs + 255) / 256 > 0x7fffffffLL) return MAXSIM_ERANGE;
+  hipLaunchKernelGGL(k_build_doc_table, dim3((unsigned)((n_docs + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     tok_offsets, doclens, pad_len, n_docs, (int4*)table);
+  return check_launch();
+}
+
+int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64_t lo, int64_t hi,
+                            int64_t* out_local, int64_t* out_global, int32_t* out_count, void* stream) {
+  if (nq < 0 || ncand < 0 || lo > hi) return MAXSIM_EINVAL;
+  if (nq == 0 || ncand == 0) return MAXSIM_OK;
+  if (!cand_global || !out_local) return MAXSIM_EINVAL;
+  hipLaunchKernelGGL(k_shard_candidates, dim3((unsigned)nq), dim3(256), 0, (hipStream_t)stream, cand_global, ncand, lo,
+                     hi, out_local, out_global, out_count);
+  return check_launch();
 }
 
 int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
@@ -250,6 +301,20 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
   hipLaunchKernelGGL(k_topk, dim3((unsigned)nq), dim3(threads), ldsb, (hipStream_t)stream, scores, pids, ncand, k,
                      P, out_scores, out_pids);
   return check_launch();
+}
+
+int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype, int Lq, const int64_t* pids, int n,
+                        int depth, float* scores_ws, int64_t* out_pids, float* out_scores, int sync, void* stream) {
+  if (!iv || n < 0 || depth < 1) return MAXSIM_EINVAL;
+  if (n == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
+  if (n > 16384) return MAXSIM_ERANGE;
+  if (!scores_ws || !out_pids || !out_scores) return MAXSIM_EINVAL;
+  int rc = rerank_impl(*iv, Q, q_dtype, nullptr, nullptr, pids, 1, n, Lq, scores_ws, (hipStream_t)stream);
+  if (rc != MAXSIM_OK) return rc;
+  rc = maxsim_topk(scores_ws, pids, 1, n, depth < n ? depth : n, out_scores, out_pids, stream);  // colbert_ranker.py:128-130
+  if (rc != MAXSIM_OK) return rc;
+  if (sync && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MAXSIM_ELAUNCH;
+  return MAXSIM_OK;
 }
 
 int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,

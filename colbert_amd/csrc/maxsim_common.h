@@ -28,6 +28,7 @@ struct Params {
   const int64_t* tok_offsets;
   const int32_t* doclens;
   const int32_t* pad_len;
+  const void* doc_table;  // optional packed descriptor rows {int64 first_row, int32 len, int32 pad_len} (maxsim_build_doc_table)
   int64_t n_docs;
   // queries
   const void* Q;
@@ -39,7 +40,8 @@ struct Params {
   int nq, ncand, Lq, h;
   float* scores;
   int32_t* argmax;  // dense training-form forward only: [nq, nd, Lq] arg-max doc token per query token, or NULL
-  // dense only
+  // dense: multiplicative masks of element type mask_dtype.  rerank: q_mask is NULL or a uint8 [nq, Lq] keep-predicate
+  // (the reference's keep_nonzero, training_utils.py:48-53), d_mask unused
   const void* q_mask;
   const void* d_mask;
   int mask_dtype;
@@ -62,17 +64,17 @@ struct Scalars {
       const int32_t* __restrict__ a_doclens, const int32_t* __restrict__ a_pad_len,                         \
       const void* __restrict__ a_Q, const int32_t* __restrict__ a_q_len, const int64_t* __restrict__ a_cand, \
       float* __restrict__ a_scores, const void* __restrict__ a_q_mask, const void* __restrict__ a_d_mask,   \
-      int32_t* __restrict__ a_argmax, const maxsim::Scalars sc
+      int32_t* __restrict__ a_argmax, const void* __restrict__ a_doc_table, const maxsim::Scalars sc
 #define KARGS_TO_PARAMS                                                                                     \
   maxsim::Params p;                                                                                         \
   p.index = a_index; p.n_tokens = sc.n_tokens; p.tok_offsets = a_tok_offsets; p.doclens = a_doclens;        \
   p.pad_len = a_pad_len; p.n_docs = sc.n_docs; p.Q = a_Q; p.q_len = a_q_len; p.cand = a_cand;               \
   p.nq = sc.nq; p.ncand = sc.ncand; p.Lq = sc.Lq; p.h = sc.h; p.scores = a_scores; p.q_mask = a_q_mask;     \
   p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk;         \
-  p.q_dtype = sc.q_dtype; p.argmax = a_argmax; p.q_tok0 = sc.q_tok0; p.accum = sc.accum
+  p.q_dtype = sc.q_dtype; p.argmax = a_argmax; p.q_tok0 = sc.q_tok0; p.accum = sc.accum; p.doc_table = a_doc_table
 #define KARGS_PASS(p)                                                                                       \
   (p).index, (p).tok_offsets, (p).doclens, (p).pad_len, (p).Q, (p).q_len, (p).cand, (p).scores, (p).q_mask, \
-      (p).d_mask, (p).argmax, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
+      (p).d_mask, (p).argmax, (p).doc_table, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
                                     (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype, (p).q_tok0, (p).accum }
 
 template <int N>
@@ -123,6 +125,40 @@ __device__ __forceinline__ float load_elem(const void* p, int64_t i) {
   return bf16_to_f32(((const uint16_t*)p)[i]);
 }
 
+// Doc metadata of one pid: first token row, length, bucket stride.  With the packed table this is ONE 16-byte load
+// (one random cache line per candidate instead of three -- it matters when a doc is a few KB, e.g. the 8-token
+// multi-view config, and it shortens a small launch's start-up).
+struct DocMeta {
+  int64_t off;
+  int len, pad;
+};
+__device__ __forceinline__ DocMeta load_doc_meta(const Params& p, int64_t pid) {
+  DocMeta m;
+  if (p.doc_table) {
+    const int4 r = ((const int4*)p.doc_table)[pid];
+    m.off = (int64_t)(((uint64_t)(uint32_t)r.y << 32) | (uint32_t)r.x);
+    m.len = r.z;
+    m.pad = r.w;
+  } else {
+    m.off = p.tok_offsets[pid];
+    m.len = p.doclens[pid];
+    m.pad = p.pad_len ? p.pad_len[pid] : m.len;
+  }
+  return m;
+}
+
+// Is query token `qtok` of query `qi` scored?  Rerank: below q_len and kept by the uint8 q_mask predicate (both
+// optional).  A dropped token is a zero query row: every similarity is exactly 0, so it adds 0 to the sum -- the same
+// value the reference gets by removing the token before search() (keep_nonzero, training_utils.py:48-53).
+template <int MODE>
+__device__ __forceinline__ bool q_token_live(const Params& p, int qi, int qtok, int qlen) {
+  bool live = qtok < qlen;
+  if constexpr (MODE == MODE_RERANK) {
+    if (p.q_mask) live = live && ((const uint8_t*)p.q_mask)[(int64_t)qi * p.Lq + (live ? qtok : 0)] != 0;
+  }
+  return live;
+}
+
 // ---------------------------------------------------------------------------------------------
 // One candidate slot, wave-uniform.
 struct Doc {
@@ -144,9 +180,10 @@ __device__ __forceinline__ Doc load_doc(const Params& p, int qi, int c) {
     int64_t pid = uni64(p.cand[(int64_t)qi * p.ncand + c]);
     bool ok = pid >= 0 && pid < p.n_docs;
     int64_t safe = ok ? pid : 0;
-    int64_t off = uni64(p.tok_offsets[safe]);
-    int len = uni(p.doclens[safe]);
-    int pad = p.pad_len ? uni(p.pad_len[safe]) : len;
+    const DocMeta dm = load_doc_meta(p, safe);
+    int64_t off = uni64(dm.off);
+    int len = uni(dm.len);
+    int pad = uni(dm.pad);
     // defensive: never stream outside the token matrix
     bool inb = off >= 0 && len >= 0 && off + len <= p.n_tokens;
     ok = ok && inb;

@@ -26,7 +26,7 @@ __global__ void __launch_bounds__(256) k_maxsim_generic(KARGS_DECL) {
   for (int mq = wave; mq < p.Lq; mq += 4) {
     float best = NEG_INF;
     int bestn = 0;
-    const bool live = mq < qlen;
+    const bool live = q_token_live<MODE>(p, qi, mq, qlen);
     float qs = 1.0f;
     if (masked) qs = load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + mq);
     const int64_t qbase = ((int64_t)qi * p.Lq + mq) * h;

@@ -1,26 +1,70 @@
 // maxsim_launch.h -- host-side launch helpers shared by the translation units of libmaxsim, and the entry points each
 // unit exports to the C-ABI file (the kernels are split over several .hip files only to compile them in parallel).
 #pragma once
+#include <atomic>
+
 #include "maxsim_common.h"
 
 namespace maxsim {
 
+// Kernels that need more than the default 64 KiB of dynamic LDS must be granted it once per (device, kernel):
+// hipFuncSetAttribute costs a few microseconds, which is a fifth of a single-query rerank call, so the grant is
+// remembered in a small lock-free table (a lost race only repeats the idempotent call).
+struct LdsGrant {
+  std::atomic<const void*> fn{nullptr};
+  std::atomic<int> bytes{0};
+};
+inline int allow_lds_slow(const void* fn, int bytes) {
+  static LdsGrant table[8][128];  // [device][open addressing over the kernels of this library]
+  auto grant = [&] {
+    return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
+  };
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return MAXSIM_ELAUNCH;
+  if (dev < 0 || dev >= 8) return grant();
+  const uintptr_t key = (uintptr_t)fn;
+  for (unsigned probe = 0; probe < 128; ++probe) {
+    LdsGrant& g = table[dev][(unsigned)((key >> 4) + probe) & 127];
+    const void* cur = g.fn.load(std::memory_order_acquire);
+    if (cur == fn) {
+      if (g.bytes.load(std::memory_order_acquire) >= bytes) return MAXSIM_OK;
+      const int rc = grant();
+      if (rc == MAXSIM_OK) g.bytes.store(bytes, std::memory_order_release);
+      return rc;
+    }
+    if (cur == nullptr) {
+      const int rc = grant();
+      const void* expect = nullptr;
+      if (rc == MAXSIM_OK && g.fn.compare_exchange_strong(expect, fn, std::memory_order_acq_rel))
+        g.bytes.store(bytes, std::memory_order_release);
+      return rc;
+    }
+  }
+  return grant();  // table full (cannot happen with this library's kernel count)
+}
 template <typename K>
 inline int allow_lds(K kernel, int bytes) {
   if (bytes <= 64 * 1024) return MAXSIM_OK;
-  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-  return e == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
+  return allow_lds_slow((const void*)kernel, bytes);
 }
 
 inline int check_launch() { return hipGetLastError() == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH; }
 
+// Tuning / ablation knobs exist only in diagnostic builds (build.sh -DMAXSIM_DIAG, loaded through MAXSIM_LIB by the
+// tools/ scripts).  The shipped library never consults the environment: a stray variable cannot select an ablation
+// kernel (those return wrong scores by design) and no launch pays for a getenv.
+#ifdef MAXSIM_DIAG
 inline int env_int(const char* name, int dflt) {
   const char* e = getenv(name);
   return e ? atoi(e) : dflt;
 }
+#define MAXSIM_KNOB(name, dflt) ([] { static const int v = ::maxsim::env_int(name, dflt); return v; }())
+#else
+#define MAXSIM_KNOB(name, dflt) (dflt)
+#endif
 
 // Docs per wave for the streaming kernels: a wave's token stream should be long (~1.5k tokens) so that the one partly
-// filled last tile, the 16 KiB query-tile load and the three dependent descriptor loads of its start-up are noise;
+// filled last tile, the 16 KiB query-tile load and the dependent descriptor loads of its start-up are noise;
 // small launches shorten it only as far as it takes to fill (nearly) one round of the 512 resident workgroup slots --
 // measured (tools/sweep_minwgs.sh, 2..32 queries x 1000 docs): against the earlier "at least 2048 workgroups" rule
 // this is 3-13 % faster on 32x180 docs, 7-17 % with the fp16 index, up to 6x on 8-token docs, within +-9 % on ragged
@@ -31,7 +75,7 @@ inline int pick_docs_per_wave(const Params& p, int waves) {
   int dpwv = (int)(1440.0 / avg + 0.5);
   if (dpwv < 1) dpwv = 1;
   if (dpwv > 64) dpwv = 64;
-  const int min_wgs = env_int("MAXSIM_MIN_WGS", 448);  // tuning knob
+  const int min_wgs = MAXSIM_KNOB("MAXSIM_MIN_WGS", 448);
   while (dpwv > 1 && (int64_t)p.nq * ((p.ncand + dpwv * waves - 1) / (dpwv * waves)) < min_wgs) dpwv = (dpwv + 1) / 2;
   return dpwv;
 }

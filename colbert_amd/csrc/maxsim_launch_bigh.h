@@ -14,7 +14,7 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
   const int KB = (p.h + 127) / 128;
   const int qbytes = QB * NPQ * KB * SUB;
   const int avail = 160 * 1024 - qbytes;
-  int dpwv = env_int("MAXSIM_DPW", 0);
+  int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);
   if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4);
   auto go = [&](auto kern, int waves, int nt) {
     p.dpw = dpwv * waves;
@@ -50,7 +50,7 @@ int launch_stream_bigh(Params& p, hipStream_t st) {
   if constexpr (MODE == MODE_DENSE) {
     constexpr int SUB = StreamTraits<DT>::TILE;
     const int qimg = NPQ * (p.h / 128) * SUB;
-    const int qb_env = env_int("MAXSIM_QB", 0);  // tuning knob
+    const int qb_env = MAXSIM_KNOB("MAXSIM_QB", 0);  // tuning knob (diagnostic builds)
     auto fits = [&](int qb) { return qb * qimg + 4 * SUB <= 160 * 1024 && qb * NPQ <= 4 && (qb_env == 0 || qb <= qb_env); };
     if (p.nq >= 4 && fits(4)) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 4>(p, st);
     if (p.nq >= 2 && fits(2)) return launch_stream_bigh_q<MODE, DT, NPQ, AM, 2>(p, st);

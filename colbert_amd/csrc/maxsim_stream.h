@@ -83,9 +83,9 @@ __device__ __forceinline__ DocLanes load_doc_lanes(const Params& p, int qi, int 
       const int64_t pid = p.cand[(int64_t)qi * p.ncand + c];
       bool ok = pid >= 0 && pid < p.n_docs;
       const int64_t safe = ok ? pid : 0;
-      const int64_t off = p.tok_offsets[safe];
-      const int len = p.doclens[safe];
-      const int pad = p.pad_len ? p.pad_len[safe] : len;
+      const DocMeta dm = load_doc_meta(p, safe);
+      const int64_t off = dm.off;
+      const int len = dm.len, pad = dm.pad;
       ok = ok && off >= 0 && len >= 0 && off + len <= p.n_tokens;  // defensive: never stream outside the matrix
       const int kind = !ok ? 2 : (len == 0 ? 1 : 0);
       d.row0 = kind == 0 ? (uint32_t)off : 0u;
@@ -551,6 +551,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     }
     prev_issued = t.kind != 0;
   }
+  if (nissued == 0) {
+    // nothing to stream: every slot of this wave is a padding slot (-inf) or an empty doc (0) -- e.g. the tail of a
+    // doc-sharded candidate row (maxsim_shard_candidates).  Retire before the 16 KiB query tile is fetched.
+    float* const srow0 = p.scores + (int64_t)qi * p.ncand + c_begin;
+    if (lane < ndoc) srow0[lane] = (p.accum ? srow0[lane] : 0.0f) + ((dl.flags & 3) == 1 ? 0.0f : NEG_INF);
+    return;
+  }
 
   // ---- query tile -> registers in MFMA B layout --------------------------------------------------------------
   // fp32: lane (n, hh) holds Q[n][32 s + 8 u + 4 hh + t]   in qv[4 s + u][t]
@@ -562,7 +569,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     int qlen = p.Lq;
     if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
     const int qtok = p.q_tok0 + r;  // this lane's query token (queries longer than 32 tokens: one launch per 32)
-    const bool live = qtok < qlen;
+    const bool live = q_token_live<MODE>(p, qi, qtok, qlen);
     const int64_t qoff = ((int64_t)qi * p.Lq + (live ? qtok : 0)) * 128;
     const float* qrow = (const float*)p.Q + qoff;
     const bool qf32 = p.q_dtype == MAXSIM_F32;  // a 16-bit query is widened element by element (start-up only)
@@ -572,7 +579,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 #pragma unroll
       for (int cb = 0; cb < (QT == 16 ? 1 : 2); ++cb) {
         const int qt16 = p.q_tok0 + 16 * cb + n16;
-        const bool live16 = qt16 < qlen;
+        const bool live16 = q_token_live<MODE>(p, qi, qt16, qlen);
         const int64_t qo = ((int64_t)qi * p.Lq + (live16 ? qt16 : 0)) * 128;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -612,7 +619,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
         int64_t e0 = qoff + 8 * hh + 16 * i;
         if constexpr (QT == QT_2X16) {
           const int tok16 = p.q_tok0 + 16 * (i >> 2) + (lane & 15);
-          lv = tok16 < qlen;
+          lv = q_token_live<MODE>(p, qi, tok16, qlen);
           e0 = ((int64_t)qi * p.Lq + (lv ? tok16 : 0)) * 128 + 8 * (4 * (i & 3) + (lane >> 4));
         }
         float q[8];
@@ -1066,6 +1073,11 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
     }
     prev_issued = t.kind != 0;
   }
+  if (nissued == 0) {  // all padding slots / empty docs: retire before the query tile is fetched
+    float* const srow0 = p.scores + (int64_t)qi * p.ncand + c_begin;
+    if (lane < ndoc) srow0[lane] = (p.accum ? srow0[lane] : 0.0f) + ((dl.flags & 3) == 1 ? 0.0f : NEG_INF);
+    return;
+  }
 
   // lane (n, kq) holds Q[16 cb + n][16 j + 4 kq + t] in qv[8 cb + j][t]
   f32x4 qv[8 * NCB];
@@ -1076,7 +1088,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
 #pragma unroll
     for (int cb = 0; cb < NCB; ++cb) {
       const int qt = p.q_tok0 + 16 * cb + n16;
-      const bool live = qt < qlen;
+      const bool live = q_token_live<MODE_RERANK>(p, qi, qt, qlen);
       const int64_t qo = ((int64_t)qi * p.Lq + (live ? qt : 0)) * 128;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {

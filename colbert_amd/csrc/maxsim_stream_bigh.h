@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       int qlen = p.Lq;
       if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
       const int qtok = p.q_tok0 + n;  // queries longer than 32 tokens: one launch per 32
-      const bool live = qtok < qlen;
+      const bool live = q_token_live<MODE>(p, qi, qtok, qlen);
       const int64_t src = ((int64_t)qi * p.Lq + (live ? qtok : 0)) * p.h + kb * 128 + c * EPC;
       const float qs = (masked && live) ? load_mask(p.q_mask, p.mask_dtype, (int64_t)qi * p.Lq + qtok) : 1.0f;
       float q[EPC];

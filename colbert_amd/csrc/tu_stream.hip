@@ -7,7 +7,7 @@ namespace {
 
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>
 int launch_stream_v(Params& p, hipStream_t st) {
-  int dpwv = env_int("MAXSIM_DPW", 0);  // tuning knob: docs per wave
+  int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);  // tuning knob (diagnostic builds): docs per wave
   if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
   p.dpw = dpwv * WAVES;
   p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
@@ -21,7 +21,7 @@ int launch_stream_v(Params& p, hipStream_t st) {
 
 template <int WAVES, int NCB, int NT>
 int launch_stream_f32h(Params& p, hipStream_t st) {
-  int dpwv = env_int("MAXSIM_DPW", 0);
+  int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);
   if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
   p.dpw = dpwv * WAVES;
   p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
@@ -34,41 +34,54 @@ int launch_stream_f32h(Params& p, hipStream_t st) {
 }
 
 // Per-wave LDS ring: fp32 1 x 16 KiB tile, 16-bit 2 x 8 KiB tiles; 4 waves per workgroup = 64 KiB, two
-// workgroups per CU.  MAXSIM_VARIANT is a diagnostic knob (DESIGN.md "Tuning knobs"): 1/2 = ablation builds.
+// workgroups per CU.  MAXSIM_VARIANT exists in diagnostic builds only (-DMAXSIM_DIAG; DESIGN.md "Tuning knobs"):
+// 1/2 = ablation kernels (timing only, WRONG scores) -- the shipped library does not even contain them.
 template <int MODE, int DT>
 int launch_stream(Params& p, hipStream_t st) {
   constexpr int NT0 = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
+  const int variant = MAXSIM_KNOB("MAXSIM_VARIANT", 0);
+  (void)variant;
   if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {
     // fp32 rerank runs on v_mfma_f32_16x16x4_f32: <= 16 query tokens as one 16-column block (half the matrix work),
     // otherwise as two.  Same flop rate as the 32x32x2 form, but half the accumulator register traffic per flop:
     // the chip is power-limited on this kernel (1.9 GHz with fetch + f32 MFMA together, 2.35 GHz with either alone),
-    // and the lighter form buys 2-3 % of clock.  MAXSIM_VARIANT=4 forces the 32x32x2 form.
-    const int v16 = env_int("MAXSIM_VARIANT", 0);
+    // and the lighter form buys 2-3 % of clock.  (diagnostic: MAXSIM_VARIANT=4 forces the 32x32x2 form)
     // short docs (the 8-token multi-view config): 16-row half tiles, two per wave in the ring -- the first rows of a
     // short stream arrive sooner and tiles straddle fewer docs: +5-7 % at 8-16 tokens per doc, -2 % from 32 up.
-    // MAXSIM_VARIANT=6 forces this kernel, 8 disables it.
+    // (diagnostic: MAXSIM_VARIANT=6 forces this kernel, 8 disables it)
     const bool short_docs = p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs;
-    if (v16 == 6 || (short_docs && v16 == 0))
+    if (variant == 6 || (short_docs && variant == 0))
       return p.Lq <= 16 ? launch_stream_f32h<4, 1, 2>(p, st) : launch_stream_f32h<4, 2, 2>(p, st);
-    if (p.Lq <= 16 && v16 != 4) {  // (Lq <= 16 implies a single query slice)
-      if (v16 == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
-      if (v16 == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
+    if (p.Lq <= 16 && variant != 4) {  // (Lq <= 16 implies a single query slice)
+#ifdef MAXSIM_DIAG
+      if (variant == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
+      if (variant == 2) return launch_stream_v<MODE, DT, 4, NT0, 2, 16>(p, st);
+#endif
       return launch_stream_v<MODE, DT, 4, NT0, 0, 16>(p, st);
     }
-    if (v16 == 0) return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
+#ifdef MAXSIM_DIAG
+    if (variant == 0 || variant == 8)
+#endif
+      return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
   }
   if constexpr (MODE == MODE_RERANK && DT != MAXSIM_F32 && DT != MAXSIM_F32_FAST) {
-    // 16-bit index and the 3 x bf16 mode of an fp32 index: v_mfma_f32_16x16x32 in two 16-column blocks (+2-3 %; the
-    // fp16-split fast mode measured 1 % slower in this form and keeps 32x32x16) (a higher sustained clock than 32x32x16 on the power
-    // cap); MAXSIM_VARIANT=4 forces the 32x32x16 form
-    if (env_int("MAXSIM_VARIANT", 0) == 0) return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
+    // 16-bit index and the 3 x bf16 mode of an fp32 index: v_mfma_f32_16x16x32 in two 16-column blocks (+2-3 %: a
+    // higher sustained clock than 32x32x16 on the power cap; the fp16-split fast mode measured 1 % slower in this form
+    // and keeps 32x32x16).  (diagnostic: MAXSIM_VARIANT=4 forces the 32x32x16 form)
+#ifdef MAXSIM_DIAG
+    if (variant == 0)
+#endif
+      return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
   }
-  switch (env_int("MAXSIM_VARIANT", 0)) {
+#ifdef MAXSIM_DIAG
+  switch (variant) {
     case 1: return launch_stream_v<MODE, DT, 4, NT0, 1>(p, st);  // no MFMA  (timing only, wrong results)
     case 2: return launch_stream_v<MODE, DT, 4, NT0, 2>(p, st);  // no DMA   (timing only, wrong results)
     case 3: return launch_stream_v<MODE, DT, 4, NT0 * 2>(p, st); // deeper ring, 1 workgroup per CU
-    default: return launch_stream_v<MODE, DT, 4, NT0>(p, st);
+    default: break;
   }
+#endif
+  return launch_stream_v<MODE, DT, 4, NT0>(p, st);
 }
 
 }  // namespace

@@ -10,6 +10,8 @@ asserts and return contract so ``ColbertRetriever.search`` (colbert/indexing/fai
 call it unchanged.
 """
 import array
+import ctypes
+import threading
 from itertools import accumulate
 
 import torch
@@ -27,6 +29,43 @@ def torch_percentile(tensor, p):
     return tensor.kthvalue(int(p * tensor.size(0) / 100.0)).values.item()
 
 
+def reference_strides(doclens):
+    """The length-bucket strides of colbert_ranker.py:36-40 for a 1-D int64 tensor of doclens."""
+    strides = [torch_percentile(doclens, p) for p in [25, 50, 75]]            # :36
+    strides.append(doclens.max().item())                                       # :39
+    return sorted(list(set(strides)))                                          # :40
+
+
+def strides_from_histogram(hist):
+    """The same strides from a histogram of doclens (``hist[v]`` = number of docs with ``v`` tokens): ``kthvalue(k)`` is
+    the smallest v whose cumulative count reaches k.  Exact, and a histogram can be summed across shards
+    (``sharded.global_strides``) where the doclens themselves would have to be gathered."""
+    hist = hist.to(torch.int64)
+    n = int(hist.sum().item())
+    cum = torch.cumsum(hist, 0)
+    out = []
+    for p in [25, 50, 75]:
+        k = int(p * n / 100.0)                                                 # torch_percentile, :238-241
+        if k < 1:
+            raise RuntimeError("kthvalue(): selected number k out of range for dimension 0")   # what the reference raises for N < 4
+        out.append(int(torch.searchsorted(cum, torch.tensor(k), right=False).item()))
+    out.append(int(torch.nonzero(hist).max().item()))                          # doclens.max()
+    return sorted(list(set(out)))
+
+
+class _Workspace:
+    """Per-thread buffers of ``rank_forward``: pinned host memory the GPU reads the pid list from and writes the top-k
+    to (no memcpy calls on the way in or out), and the device score vector."""
+
+    def __init__(self, device):
+        self.pin_in = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
+        self.pin_out_p = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
+        self.pin_out_s = torch.empty(BSIZE, dtype=torch.float32).pin_memory()
+        self.scores = torch.empty(BSIZE, dtype=torch.float32, device=device)
+        self.in_ptr, self.out_p_ptr, self.out_s_ptr = self.pin_in.data_ptr(), self.pin_out_p.data_ptr(), self.pin_out_s.data_ptr()
+        self.scores_ptr = self.scores.data_ptr()
+
+
 class ColbertRanker:
     """``ColbertRanker(index_path, model=None, dim=None)`` as in colbert_ranker.py:16; ``model`` is accepted for
     signature compatibility (the fused kernel replaces ``model.score``).  Keyword-only extras:
@@ -38,10 +77,13 @@ class ColbertRanker:
                             "bf16x3" (both operands cut exactly into three bf16 pieces, six piece products on the bf16
                             matrix pipe: fp32-class accuracy, no magnitude limit, ~7 % faster) or "fast" (fp16 hi+lo
                             pieces, three products, |error| ~1e-6 on a score, needs |x| < 65504, ~11 % faster)
+    strides               : length-bucket strides to use instead of the percentiles of THIS index's doclens
+                            (colbert_ranker.py:36-40).  A doc-shard must be given the strides of the whole index
+                            (``sharded.global_strides``): the 0-floor depends on them (:90, :108-109)
     """
 
     def __init__(self, index_path=None, model=None, dim=None, *, parts=None, parts_doclens=None, device="cuda",
-                 index_dtype=torch.float16, fp32_mode="exact"):
+                 index_dtype=torch.float16, fp32_mode="exact", strides=None):
         part_iter = None
         if index_path is not None:
             _, parts_paths, _ = index_io.get_parts(index_path)                # :18
@@ -74,10 +116,10 @@ class ColbertRanker:
             offset = endpos
             del part
         assert self.tensor is not None and offset == self.num_embeddings
-        self.init_ranker(doclens)
+        self.init_ranker(doclens, strides)
 
     @classmethod
-    def from_device_tensor(cls, tensor, doclens, model=None, fp32_mode="exact"):
+    def from_device_tensor(cls, tensor, doclens, model=None, fp32_mode="exact", strides=None):
         """Adopts an index that already sits in HBM: ``tensor`` [sum(doclens), dim] (fp32/fp16/bf16, contiguous) is
         used as is, no copy.  (Synthetic benchmarks; shards handed over by another component.)"""
         self = cls.__new__(cls)
@@ -91,30 +133,54 @@ class ColbertRanker:
         self.fp32_mode = fp32_mode
         self.num_embeddings = tensor.size(0)
         self.tensor = tensor
-        self.init_ranker([int(x) for x in doclens])
+        self.init_ranker([int(x) for x in doclens], strides)
         return self
 
-    def init_ranker(self, doclens):                                           # :31-43
+    def init_ranker(self, doclens, strides=None):                             # :31-43
         pfx = [0] + list(accumulate(doclens))
         self.doclens = torch.tensor(doclens, dtype=torch.int64)
         self.doclens_pfxsum = torch.tensor(pfx, dtype=torch.int64)
         self.dim = self.tensor.size(-1)
-        self.strides = [torch_percentile(self.doclens, p) for p in [25, 50, 75]]   # :36
-        self.strides.append(self.doclens.max().item())                              # :39
-        self.strides = sorted(list(set(self.strides)))                              # :40
-        # the bucket stride each doc would be padded to (:90): smallest stride >= doclen
-        assignments = (self.doclens.unsqueeze(1) > torch.tensor(self.strides).unsqueeze(0) + 1e-6).sum(-1)
-        pad_len = torch.tensor(self.strides)[assignments]
         dev = self.device
         self.d_doclens = self.doclens.to(dev, torch.int32)
         self.d_offsets = self.doclens_pfxsum[:-1].contiguous().to(dev)
-        self.d_pad_len = pad_len.to(dev, torch.int32)
         self.n_docs = len(doclens)
+        self._tls = threading.local()
+        self.set_strides(reference_strides(self.doclens) if strides is None else strides)
+
+    def set_strides(self, strides):
+        """(Re)derives the per-doc bucket stride -- the length the reference would pad the doc to, :90: the smallest
+        stride >= doclen -- and the packed descriptor table the kernels read.  Called with the strides of the WHOLE index
+        on a doc-shard."""
+        self.strides = sorted(set(int(x) for x in strides))
+        st = torch.tensor(self.strides)
+        assert int(self.doclens.max().item()) <= self.strides[-1], "a doc is longer than the largest stride"
+        assignments = (self.doclens.unsqueeze(1) > st.unsqueeze(0) + 1e-6).sum(-1)     # :90
+        dev = self.device
+        self.d_pad_len = st[assignments].to(dev, torch.int32)
+        self.d_doc_table = None
+        if dev.type == "cuda":
+            nbytes = int(_lib.lib.maxsim_doc_table_bytes(self.n_docs))
+            self.d_doc_table = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = _lib.lib.maxsim_build_doc_table(_ptr(self.d_offsets), _ptr(self.d_doclens), _ptr(self.d_pad_len),
+                                                     self.n_docs, _ptr(self.d_doc_table), _stream(dev))
+            _lib.check(rc, "maxsim_build_doc_table")
+        self._iv = self._index_view()
+
+    def _index_view(self):
+        idt = _DT[self.tensor.dtype]
+        if idt == _lib.F32:
+            idt = {"exact": _lib.F32, "fast": _lib.F32_FAST, "bf16x3": _lib.F32_BF16X3}[getattr(self, "fp32_mode", "exact")]
+        return _lib.IndexView(_ptr(self.tensor), idt, self.dim, self.num_embeddings, _ptr(self.d_offsets),
+                              _ptr(self.d_doclens), _ptr(self.d_pad_len), self.n_docs, _ptr(self.d_doc_table))
 
     # ------------------------------------------------------------------------------------------
-    def score_candidates(self, Q, cand_pids, q_len=None):
+    def score_candidates(self, Q, cand_pids, q_len=None, q_mask=None):
         """Q [nq, Lq, h] (token-major), cand_pids [nq, ncand] int64 LOCAL pids (<0 = padding slot)
-        -> scores [nq, ncand] fp32 on the device."""
+        -> scores [nq, ncand] fp32 on the device.  ``q_len`` [nq] drops the tokens from that position on, ``q_mask``
+        [nq, Lq] (0 = dropped) any tokens -- the batched form of the per-query ``keep_nonzero`` (training_utils.py:48-53)
+        the reference applies to ``q_active_padding`` at dense_server_client.py:45."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("colbert_amd scores on the GPU only: the index must live in HBM (libmaxsim has no CPU path)")
@@ -127,31 +193,25 @@ class ColbertRanker:
         assert cand.dim() == 2 and cand.size(0) == nq
         ncand = cand.size(1)
         ql = None if q_len is None else q_len.to(device=dev, dtype=torch.int32).contiguous()
+        qm = None
+        if q_mask is not None:
+            assert tuple(q_mask.shape) == (nq, Lq), (tuple(q_mask.shape), (nq, Lq))
+            qm = (q_mask.to(dev) != 0).to(torch.uint8).contiguous()            # q_word_mask.bool(), training_utils.py:50
         scores = torch.empty(nq, ncand, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            idt = _DT[self.tensor.dtype]
-            if idt == _lib.F32:
-                idt = {"exact": _lib.F32, "fast": _lib.F32_FAST, "bf16x3": _lib.F32_BF16X3}[getattr(self, "fp32_mode", "exact")]
-            rc = _lib.lib.maxsim_rerank(_ptr(self.tensor), idt, self.num_embeddings,
-                                        _ptr(self.d_offsets), _ptr(self.d_doclens), _ptr(self.d_pad_len),
-                                        self.n_docs, _ptr(Q), _DT[qdt], _ptr(ql), _ptr(cand), nq, ncand, Lq, h,
-                                        _ptr(scores), _stream(dev))
+            rc = _lib.lib.maxsim_rerank_ex(ctypes.byref(self._iv), _ptr(Q), _DT[qdt], _ptr(ql), _ptr(qm), _ptr(cand),
+                                           nq, ncand, Lq, _ptr(scores), _stream(dev))
         if rc == _lib.EEMPTY:
             raise AssertionError("len(pids) > 0")  # colbert_ranker.py:76
-        _lib.check(rc, "maxsim_rerank")
+        _lib.check(rc, "maxsim_rerank_ex")
         return scores
 
-    def topk(self, scores, pids, k, _packed=None):
-        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k]).
-        (``_packed``: a uint8 buffer of nq*k*12 bytes that receives both outputs -- one D2H copy for rank_forward.)"""
+    def topk(self, scores, pids, k):
+        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k])."""
         dev = scores.device
         nq, n = scores.shape
-        if _packed is None:
-            out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
-            out_p = torch.empty(nq, k, dtype=torch.int64, device=dev)
-        else:
-            out_p = _packed[: nq * k * 8].view(torch.int64).view(nq, k)
-            out_s = _packed[nq * k * 8:].view(torch.float32).view(nq, k)
+        out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
+        out_p = torch.empty(nq, k, dtype=torch.int64, device=dev)
         scores = scores.contiguous()
         pids = None if pids is None else pids.to(device=dev, dtype=torch.int64).contiguous()
         with torch.cuda.device(dev):
@@ -159,10 +219,10 @@ class ColbertRanker:
         _lib.check(rc, "maxsim_topk")
         return out_p, out_s
 
-    def rerank_batch(self, Q, cand_pids, depth=10, q_len=None):
+    def rerank_batch(self, Q, cand_pids, depth=10, q_len=None, q_mask=None):
         """Batched form of the per-query loop dense_server_client.py:44-48: one launch for all queries.
         Returns device tensors (pids [nq,k], scores [nq,k]) with k = min(depth, ncand)."""
-        scores = self.score_candidates(Q, cand_pids, q_len)
+        scores = self.score_candidates(Q, cand_pids, q_len, q_mask)
         k = min(int(depth), scores.size(1))
         return self.topk(scores, cand_pids, k)
 
@@ -196,24 +256,51 @@ class ColbertRanker:
             # the reference's per-candidate-query branch (:103) takes row [0] of an all-pairs result (:112) --
             # a latent bug that is never exercised (faiss_indexers.py:232-234 always passes one query).
             raise NotImplementedError("rank_forward with one query per candidate is not exercised by the reference")
-        if type(pids) is list:
-            n_pids = len(pids)
-            try:        # 1000 python ints: 14 us through array('q') against 50-75 us for torch.tensor(list)
-                pids_t = torch.frombuffer(array.array("q", pids), dtype=torch.int64)
-            except (TypeError, OverflowError):
-                pids_t = torch.tensor(pids)
-        else:
-            pids_t, n_pids = pids, len(pids)
-        Qt = Q.to(self.device).permute(0, 2, 1)                               # :78, :111 -> [1, Lq, h]
-        cand = pids_t.to(self.device, torch.int64).view(1, -1)
-        scores = self.score_candidates(Qt, cand)
+        n_pids = len(pids)
+        dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("colbert_amd scores on the GPU only: the index must live in HBM (libmaxsim has no CPU path)")
         k = min(int(depth), n_pids)
-        packed = torch.empty(k * 12, dtype=torch.uint8, device=self.device)   # pids and scores leave in ONE copy
-        top_p, top_s = self.topk(scores, cand, k, _packed=packed)             # :128-130
-        if output_D_embedding:                                                # :131-136
-            return self._output_D(top_p[0], k)
-        host = packed.cpu()
-        return host[: k * 8].view(torch.int64).tolist(), host[k * 8:].view(torch.float32).tolist()
+        Qt = Q.permute(0, 2, 1)                                               # :111 -> [1, Lq, h]; a view of the caller's q
+        qdt = Qt.dtype if Qt.dtype in (torch.float16, torch.bfloat16) else torch.float32
+        Qt = Qt.to(device=dev, dtype=qdt).contiguous()                        # :78 (a no-op for faiss_indexers.py:232-233)
+        assert Qt.size(2) == self.dim, (Qt.size(2), self.dim)
+        if n_pids > BSIZE or output_D_embedding:
+            pids_t = torch.tensor(pids) if type(pids) is list else pids
+            cand = pids_t.to(dev, torch.int64).view(1, -1)
+            scores = self.score_candidates(Qt, cand)
+            top_p, top_s = self.topk(scores, cand, k)                         # :128-130
+            if output_D_embedding:                                            # :131-136
+                return self._output_D(top_p[0], k)
+            return top_p[0].tolist(), top_s[0].tolist()
+        # the online call: ONE library call (rerank + top-k enqueued back to back, then a stream sync).  The pid list goes
+        # in and the top-k comes out through pinned host buffers the kernels access directly: no memcpy calls, no
+        # allocations (per-thread workspace), no device tensors created
+        ws = getattr(self._tls, "ws", None)
+        if ws is None:
+            ws = self._tls.ws = _Workspace(dev)
+        if type(pids) is list:
+            try:        # 1000 python ints: 14 us through array('q') against 50-75 us for torch.tensor(list)
+                a = array.array("q", pids)
+                ctypes.memmove(ws.in_ptr, a.buffer_info()[0], 8 * n_pids)
+            except (TypeError, OverflowError):
+                ws.pin_in[:n_pids] = torch.tensor(pids)
+            pid_ptr = ws.in_ptr
+        elif pids.is_cuda:
+            pid_keep = pids.to(dev, torch.int64).contiguous()
+            pid_ptr = pid_keep.data_ptr()
+        else:
+            ws.pin_in[:n_pids] = pids
+            pid_ptr = ws.in_ptr
+        if torch.cuda.current_device() != dev.index and dev.index is not None:
+            with torch.cuda.device(dev):
+                rc = _lib.lib.maxsim_rank_forward(ctypes.byref(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids,
+                                                  k, ws.scores_ptr, ws.out_p_ptr, ws.out_s_ptr, 1, _stream(dev))
+        else:
+            rc = _lib.lib.maxsim_rank_forward(ctypes.byref(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids,
+                                              k, ws.scores_ptr, ws.out_p_ptr, ws.out_s_ptr, 1, _stream(dev))
+        _lib.check(rc, "maxsim_rank_forward")
+        return ws.pin_out_p[:k].tolist(), ws.pin_out_s[:k].tolist()
 
     def _output_D(self, top_pids, k):
         """colbert_ranker.py:131-136: padded D [k, S, h] and mask of the top docs.  The reference's

@@ -1,0 +1,50 @@
+"""Batched retrieve driver: the inner loop of ``DenseRetrieverServer.retrieve``
+(reference: colbert/training/dense_server_client.py:44-48) together with ``ColbertRetriever.search``
+(colbert/indexing/faiss_indexers.py:224-235) for a whole batch of queries at once.
+
+Per query the reference does: ``keep_nonzero`` (drop the tokens ``q_active_padding`` zeroes -- punctuation and [SEP]
+sit MID-sequence, colbert/modeling/tokenizers.py:36) -> ANN search of the live tokens -> embedding ids -> distinct pids
+(``emb2pid`` + ``set()``, colbert/ranking/colbert_ranker.py:176-229) -> ``rank_forward`` -> ``(pids, scores)``.
+Here every step after the ANN search is one launch for the batch: ids -> distinct pids (``maxsim_embedding_ids_to_pids``),
+fused rerank with the keep-mask as a per-token predicate (``maxsim_rerank_ex``; nothing is compacted), top-k, and ONE
+device->host copy.  The ANN search itself is third-party (FAISS) and stays outside: pass its result, or a callable.
+"""
+import torch
+
+
+def retrieve_batch(ranker, Q, q_active_padding, topk, embedding_ids=None, ann_search=None, faiss_depth=None):
+    """Q [bs, Lq, h] (the encoder's output, dense_server_client.py:43), q_active_padding [bs, Lq] 0/1.
+
+    Candidates come from ONE of
+      embedding_ids [bs, Lq, faiss_depth] int64 : the ANN neighbours (token rows of the index) of every query token;
+                      rows of dropped tokens are ignored, -1 entries are skipped (FAISS pads with -1)
+      ann_search(q_live [n_live, h], faiss_depth) -> [n_live, faiss_depth] int64 : called once with the live tokens of
+                      the whole batch, in batch order -- the reference, too, searches live tokens only
+                      (``faiss_index.search``, colbert_ranker.py:200)
+    Returns the reference's per-query ``pid_scores``: a list of ``(pids: list[int], scores: list[float])`` sorted by score
+    descending, at most ``topk`` long (shorter when a query has fewer distinct candidates).
+    """
+    assert Q.dim() == 3 and tuple(q_active_padding.shape) == tuple(Q.shape[:2])
+    dev = ranker.device
+    bs, Lq, _ = Q.shape
+    keep = (q_active_padding.to(dev) != 0)
+    if embedding_ids is None:
+        if ann_search is None or faiss_depth is None:
+            raise ValueError("give embedding_ids, or ann_search and faiss_depth")
+        live = ann_search(Q.to(dev)[keep], int(faiss_depth))
+        live = torch.as_tensor(live).to(device=dev, dtype=torch.int64)
+        embedding_ids = torch.full((bs, Lq, live.size(-1)), -1, dtype=torch.int64, device=dev)
+        embedding_ids[keep] = live
+    else:
+        embedding_ids = embedding_ids.to(device=dev, dtype=torch.int64)
+        assert embedding_ids.dim() == 3 and tuple(embedding_ids.shape[:2]) == (bs, Lq)
+        embedding_ids = torch.where(keep.unsqueeze(-1), embedding_ids, torch.full_like(embedding_ids, -1))
+    cand, counts = ranker.embedding_ids_to_pids(embedding_ids.reshape(bs, -1))       # colbert_ranker.py:178, :212-229
+    k = min(int(topk), cand.size(1))
+    top_p, top_s = ranker.rerank_batch(Q, cand, depth=k, q_mask=keep)                 # :75-137 for every query
+    host_p, host_s, host_n = top_p.cpu(), top_s.cpu(), counts.cpu()
+    out = []
+    for i in range(bs):
+        n = min(k, int(host_n[i]))
+        out.append((host_p[i, :n].tolist(), host_s[i, :n].tolist()))
+    return out

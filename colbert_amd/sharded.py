@@ -5,11 +5,19 @@ the candidates that fall in its range and takes a local top-k; ONE all_gather of
 (RCCL over xGMI when the backend is ``nccl``; 12 B x nq x k per rank -- latency-bound) is followed by a per-query
 ``world*k -> k`` merge on every rank.  There is no other collective on this path.
 
+Parity with the UNSHARDED reference: the reference derives its length-bucket strides from the doclens of the whole
+index (colbert_ranker.py:36-40) and a doc's 0-floor depends on them (:90, :108-109), so every shard must bucket by the
+GLOBAL strides, not by the percentiles of its own docs: ``global_strides`` (one all_reduce of a doclen histogram at
+load time) and ``ColbertRanker(strides=...)`` / ``set_strides``; ``ShardedRanker`` does this by itself.
+
 ``score_fn`` / ``topk_fn`` are injectable so the partition/gather/merge logic can be exercised on CPU ranks
 (``gloo``) in tests with the oracle as scorer; the product default is the HIP path of the local ``ColbertRanker``.
 """
 import torch
 import torch.distributed as dist
+
+from . import _lib
+from .ranker import strides_from_histogram
 
 NEG_INF = float("-inf")
 
@@ -25,6 +33,47 @@ def localize(cand_global, lo, hi):
     """Global candidate pids -> local pids of this shard; out-of-range entries become -1 (padding slots)."""
     inr = (cand_global >= lo) & (cand_global < hi)
     return torch.where(inr, cand_global - lo, torch.full_like(cand_global, -1)), inr
+
+
+def shard_candidates(cand_global, lo, hi):
+    """This shard's candidates moved to the front of every row, in list order, as (local pids, global pids), both
+    ``[nq, ncand]`` with -1 in the tail.  The row width is NOT cut (no host sync): the rerank kernel's trailing
+    all-padding waves retire at once.  Device tensors run ``maxsim_shard_candidates``; CPU tensors (the gloo tests,
+    whose scorer is injected) the same stable partition in torch."""
+    nq, ncand = cand_global.shape
+    if cand_global.is_cuda:
+        cg = cand_global.to(torch.int64).contiguous()
+        loc, gp = torch.empty_like(cg), torch.empty_like(cg)
+        with torch.cuda.device(cg.device):
+            rc = _lib.lib.maxsim_shard_candidates(cg.data_ptr(), nq, ncand, int(lo), int(hi), loc.data_ptr(), gp.data_ptr(),
+                                                  None, torch.cuda.current_stream(cg.device).cuda_stream)
+        _lib.check(rc, "maxsim_shard_candidates")
+        return loc, gp
+    loc, inr = localize(cand_global, lo, hi)
+    gp = torch.where(inr, cand_global, torch.full_like(cand_global, -1))
+    order = torch.argsort((~inr).to(torch.int8), dim=1, stable=True)
+    return torch.gather(loc, 1, order), torch.gather(gp, 1, order)
+
+
+def global_strides(local_doclens, group=None, device=None):
+    """The reference's length-bucket strides (colbert_ranker.py:36-40: 25/50/75th percentile by ``kthvalue`` and the
+    maximum) of the WHOLE index from each rank's local doclens: an all_reduce(MAX) of the largest doclen, then an
+    all_reduce(SUM) of the doclen histogram; the k-th smallest value is read off the cumulative histogram -- exact.
+    ``device``: where the collective's tensors live (a CUDA device for the ``nccl`` backend).  Without an initialised
+    process group this is the single-index rule."""
+    dl = torch.as_tensor(local_doclens, dtype=torch.int64)
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    mx = torch.tensor([int(dl.max().item()) if dl.numel() else 0], dtype=torch.int64)
+    if distributed:
+        if device is None and dist.get_backend(group) == "nccl":
+            device = torch.device("cuda", torch.cuda.current_device())
+        mx = mx.to(device) if device is not None else mx
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    hist = torch.bincount(dl, minlength=int(mx.item()) + 1)
+    if distributed:
+        hist = hist.to(device) if device is not None else hist
+        dist.all_reduce(hist, op=dist.ReduceOp.SUM, group=group)
+    return strides_from_histogram(hist.cpu())
 
 
 def all_gather_topk(top_s, top_p, world, group=None):
@@ -54,40 +103,43 @@ def merge_gathered(all_scores, all_pids, k, topk_fn):
 
 
 class ShardedRanker:
-    def __init__(self, local_ranker, lo, hi, group=None, score_fn=None, topk_fn=None):
+    def __init__(self, local_ranker, lo, hi, group=None, score_fn=None, topk_fn=None, sync_strides=True):
         self.local = local_ranker
         self.lo, self.hi = int(lo), int(hi)
         self.group = group
         self.score_fn = score_fn if score_fn is not None else local_ranker.score_candidates
         self.topk_fn = topk_fn if topk_fn is not None else local_ranker.topk
         self.force_exchange = False   # diagnostic: run the exchange + merge even at world size 1 (bench.py --force-dist)
+        self.exchange_events = None   # diagnostic: a list here collects (start, stop) HIP events of every exchange + merge
+        # bucket by the strides of the whole index (see the module docstring); every rank must construct its
+        # ShardedRanker at the same point (two small all_reduces)
+        if sync_strides and hasattr(local_ranker, "set_strides") and self._world() > 1:
+            dev = local_ranker.device if local_ranker.device.type == "cuda" else None
+            local_ranker.set_strides(global_strides(local_ranker.doclens, group, dev))
 
-    def local_topk(self, Q, cand_global, depth, q_len=None, compact=True):
-        cand_local, inr = localize(cand_global, self.lo, self.hi)
-        gp = torch.where(inr, cand_global, torch.full_like(cand_global, -1))
+    def local_topk(self, Q, cand_global, depth, q_len=None, q_mask=None):
+        """Scores this shard's share of every query's GLOBAL candidate list and returns its local top-k with global pids:
+        (pids [nq,k], scores [nq,k]); slots beyond a query's local candidates are (-1, -inf)."""
         k = min(int(depth), cand_global.size(1))
-        if compact and cand_global.size(1) > k:
-            # a shard owns ~1/world of each list: move its candidates to the front and cut the width to the longest
-            # local list (never below k, so the [nq, k] gather shape is the same on every rank) -- otherwise most
-            # descriptor lanes of the rerank kernel would hold padding slots
-            order = torch.argsort((~inr).to(torch.int8), dim=1, stable=True)
-            width = max(int(inr.sum(1).max().item()), k)
-            order = order[:, :width]
-            cand_local = torch.gather(cand_local, 1, order)
-            gp = torch.gather(gp, 1, order)
-        scores = self.score_fn(Q, cand_local, q_len) if q_len is not None else self.score_fn(Q, cand_local)
+        cand_local, gp = shard_candidates(cand_global, self.lo, self.hi)
+        kw = {}
+        if q_len is not None:
+            kw["q_len"] = q_len
+        if q_mask is not None:
+            kw["q_mask"] = q_mask
+        scores = self.score_fn(Q, cand_local, **kw)
         gp = gp.to(scores.device)
-        return self.topk_fn(scores, gp, k)          # (pids [nq,k] global, scores [nq,k]); padding slots = (-1, -inf)
+        return self.topk_fn(scores, gp, k)
 
     def _world(self):
         if not (dist.is_available() and dist.is_initialized()):
             return 1
         return dist.get_world_size(self.group)
 
-    def rerank_batch(self, Q, cand_global, depth=10, q_len=None):
+    def rerank_batch(self, Q, cand_global, depth=10, q_len=None, q_mask=None):
         """Every rank passes the same Q [nq,Lq,h] and global candidate lists [nq,ncand]; returns the global
         top-``depth`` (pids, scores) on every rank."""
-        top_p, top_s = self.local_topk(Q, cand_global, depth, q_len)
+        top_p, top_s = self.local_topk(Q, cand_global, depth, q_len, q_mask)
         world = self._world()
         if world == 1:
             return top_p, top_s
@@ -120,12 +172,18 @@ class _Exchange:
         ready = torch.cuda.Event()
         ready.record(main)
         self._inputs = (top_p, top_s)          # kept alive until result(): they were allocated on the caller's stream
+        timing = getattr(sr, "exchange_events", None)     # bench.py: a list that receives (start, stop) event pairs
         with torch.cuda.stream(sr._side):
             sr._side.wait_event(ready)
+            if timing is not None:
+                t0 = torch.cuda.Event(enable_timing=True)
+                t0.record(sr._side)
             gs, gp = all_gather_topk(top_s, top_p, world, sr.group)
             self.out = merge_gathered(gs, gp, depth, sr.topk_fn)
-            self.done = torch.cuda.Event()
+            self.done = torch.cuda.Event(enable_timing=timing is not None)
             self.done.record(sr._side)
+            if timing is not None:
+                timing.append((t0, self.done))
 
     def result(self):
         if self.done is not None:

@@ -14,6 +14,13 @@
  *   maxsim_topk         <- sort(descending)+[:depth]                  colbert/ranking/colbert_ranker.py:128-130
  *                          (also the per-query merge after the doc-sharded RCCL all-gather)
  *   maxsim_embedding_ids_to_pids <- ColbertIndex.embedding_ids_to_pids colbert/ranking/colbert_ranker.py:212-229
+ *   maxsim_rerank_ex    <- maxsim_rerank + the per-query keep_nonzero   colbert/training/training_utils.py:48-53,
+ *                          of the batched driver loop                   colbert/training/dense_server_client.py:44-45
+ *   maxsim_rank_forward <- ONE call of ColbertRanker.rank_forward       colbert/ranking/colbert_ranker.py:75-137
+ *                          (the reference's online call shape, colbert/indexing/faiss_indexers.py:234)
+ *   maxsim_build_doc_table <- index state set up by init_ranker         colbert/ranking/colbert_ranker.py:31-43
+ *   maxsim_shard_candidates <- no reference counterpart (its rerank is single-GPU, colbert_ranker.py:154): the
+ *                          per-rank candidate filter of the doc-sharded path
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (e.g. torch tensors); the library allocates
@@ -32,7 +39,8 @@
 extern "C" {
 #endif
 
-#define MAXSIM_VERSION 100 /* 0.1.0 */
+#define MAXSIM_VERSION 110 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
+                              maxsim_shard_candidates, maxsim_build_doc_table */
 
 /* element types of Q / D / index */
 #define MAXSIM_F32 0
@@ -155,6 +163,72 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
  */
 int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,
                                  int64_t n_tokens, int64_t* out_pids, int32_t* out_count, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
+ * Index view: everything the rerank entry points need to know about one HBM-resident (shard of an) index, passed as
+ * one struct in HOST memory (read during the call, not retained).  The first seven fields are the index arguments of
+ * maxsim_rerank; `doc_table` is optional.
+ */
+typedef struct maxsim_index_view {
+  const void* index;          /* [n_tokens, h] token matrix, element type index_dtype */
+  int32_t index_dtype;        /* MAXSIM_F32 / F16 / BF16 / F32_FAST / F32_BF16X3 */
+  int32_t h;                  /* embedding width */
+  int64_t n_tokens;
+  const int64_t* tok_offsets; /* [n_docs] */
+  const int32_t* doclens;     /* [n_docs] */
+  const int32_t* pad_len;     /* [n_docs] or NULL */
+  int64_t n_docs;
+  const void* doc_table;      /* NULL, or n_docs packed 16-byte rows written by maxsim_build_doc_table from the three
+                                 arrays above: the kernels then read one cache line per candidate instead of three */
+} maxsim_index_view;
+
+/* Bytes of the packed descriptor table of n_docs docs (16 per doc). */
+int64_t maxsim_doc_table_bytes(int64_t n_docs);
+/* table[pid] = {int64 tok_offsets[pid], int32 doclens[pid], int32 pad_len ? pad_len[pid] : doclens[pid]}.
+ * `table` must be 16-byte aligned device memory of maxsim_doc_table_bytes(n_docs) bytes.  Done once per index
+ * (colbert_ranker.py:31-43 computes the same per-doc state at load time). */
+int maxsim_build_doc_table(const int64_t* tok_offsets, const int32_t* doclens, const int32_t* pad_len,
+                           int64_t n_docs, void* table, void* stream);
+
+/*
+ * maxsim_rerank with the index passed as a view and one more optional argument:
+ *   q_mask [nq, Lq] uint8 or NULL: query token m of query q is scored iff m < q_len[q] (when given) AND q_mask[q,m] != 0.
+ * This is the reference's per-query `keep_nonzero` (training_utils.py:48-53, applied at dense_server_client.py:45 to
+ * the tokenizer's q_active_padding, which zeroes punctuation and [SEP] MID-sequence, tokenizers.py:36) for a whole
+ * batch without compacting Q: a dropped token behaves as a zero query row, whose similarities are all exactly 0 and
+ * add 0 to the sum -- the value the reference gets by removing the token.
+ * Everything else (shapes, padding slots, the 0-floor, error codes, fast paths) is as maxsim_rerank.
+ */
+int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
+                     const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
+                     void* stream);
+
+/*
+ * One ColbertRanker.rank_forward (colbert_ranker.py:75-137) in one call: rerank of ONE query against n candidate
+ * pids followed by the descending top-`depth` -- the reference's online call (faiss_indexers.py:234), where per-call
+ * host overhead, not bandwidth, dominates.  Both kernels are enqueued back to back on `stream`.
+ *   Q          [Lq, h] token-major, element type q_dtype (the shim undoes the reference's [1,h,Lq] permute)
+ *   pids       [n] int64, any memory the GPU can read: device memory, or PINNED host memory (hipHostMalloc /
+ *              torch pin_memory), which saves the H2D copy call
+ *   scores_ws  [n] float32 device scratch (the full score vector, colbert_ranker.py:122, is left there)
+ *   out_pids   [k] int64 and out_scores [k] float32, k = min(depth, n): device memory or pinned host memory (the top-k
+ *              kernel then writes the result straight to the host; no D2H copy call)
+ *   sync       != 0: hipStreamSynchronize(stream) before returning (results are then visible to the host)
+ * n == 0 -> MAXSIM_EEMPTY (assert len(pids) > 0, colbert_ranker.py:76); n <= 16384 (BSIZE, colbert_ranker.py:11).
+ */
+int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype, int Lq, const int64_t* pids, int n,
+                        int depth, float* scores_ws, int64_t* out_pids, float* out_scores, int sync, void* stream);
+
+/*
+ * Doc-sharded rerank, per-rank candidate filter (the reference reranks on one GPU only): this rank owns
+ * the global pid range [lo, hi).  Per query, the in-range entries of cand_global [nq, ncand] are moved to the front of
+ * the row in list order (stable) -- as local pids (pid - lo) in out_local and unchanged in out_global (may be NULL) --
+ * and the rest of both rows is -1 (a padding slot for maxsim_rerank: score -inf, no tokens read).  out_count [nq]
+ * (may be NULL) receives the number of in-range entries.  out_local may alias cand_global (in-place).
+ * The row width stays ncand, so nothing has to be read back to size the rerank launch.
+ */
+int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64_t lo, int64_t hi,
+                            int64_t* out_local, int64_t* out_global, int32_t* out_count, void* stream);
 
 #ifdef __cplusplus
 }

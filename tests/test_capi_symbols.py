@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.lib.maxsim_version() == 100
+    assert lib.lib.maxsim_version() == 110
     assert lib.strerror(0) == "ok"
     for code in (-1, -2, -3, -4):
         assert lib.strerror(code) not in ("ok", "unknown error")
@@ -51,6 +51,22 @@ def test_validation_without_launch(lib):
     assert L.maxsim_rerank(None, 7, 0, None, None, None, 0, None, 0, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
     assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, 5, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
     assert L.maxsim_rerank(None, 0, 0, None, None, None, 0, None, 0, None, None, 1, 1, 32, 128, None, None) == lib.EINVAL
+    # the view-based entry points validate the same way (and reject a missing view)
+    iv = lib.IndexView(None, 0, 128, 0, None, None, None, 0, None)
+    assert L.maxsim_rerank_ex(None, None, 0, None, None, None, 1, 1, 32, None, None) == lib.EINVAL
+    assert L.maxsim_rerank_ex(ctypes.byref(iv), None, 0, None, None, None, 1, 0, 32, None, None) == lib.EEMPTY
+    assert L.maxsim_rerank_ex(ctypes.byref(iv), None, 0, None, None, None, 0, 1, 32, None, None) == lib.OK
+    assert L.maxsim_rerank_ex(ctypes.byref(iv), None, 0, None, None, None, 1, 1, 32, None, None) == lib.EINVAL
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 0, 10, None, None, None, 0, None) == lib.EEMPTY
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 20000, 10, None, None, None, 0, None) == lib.ERANGE
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 5, 0, None, None, None, 0, None) == lib.EINVAL
+    assert L.maxsim_rank_forward(None, None, 0, 32, None, 5, 1, None, None, None, 0, None) == lib.EINVAL
+    assert L.maxsim_doc_table_bytes(1000) == 16000 and L.maxsim_doc_table_bytes(0) == 0
+    assert L.maxsim_build_doc_table(None, None, None, 0, None, None) == lib.OK
+    assert L.maxsim_build_doc_table(None, None, None, 4, None, None) == lib.EINVAL
+    assert L.maxsim_shard_candidates(None, 0, 10, 0, 5, None, None, None, None) == lib.OK
+    assert L.maxsim_shard_candidates(None, 2, 10, 5, 0, None, None, None, None) == lib.EINVAL
+    assert L.maxsim_shard_candidates(None, 2, 10, 0, 5, None, None, None, None) == lib.EINVAL
     # topk
     assert L.maxsim_topk(None, None, 1, 0, 1, None, None, None) == lib.EEMPTY
     assert L.maxsim_topk(None, None, 1, 20000, 1, None, None, None) == lib.ERANGE

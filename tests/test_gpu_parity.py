@@ -285,7 +285,12 @@ def test_rerank_random_vs_oracle(ca, cfg):
     for qi in range(cfg["nq"]):
         ep, es = ref.rank_forward(Q[qi:qi + 1].permute(0, 2, 1), cand[qi].tolist(), depth=10)
         np.testing.assert_allclose(ts[qi].cpu().numpy(), np.array(es), rtol=0, atol=atol)
-        assert set(tp[qi].tolist()) == set(ep) or np.allclose(sorted(es)[:1], sorted(ts[qi].tolist())[:1], atol=atol)
+        # pid sets agree except among candidates whose oracle score lies within atol of the k-th score (the only place
+        # where a rounding difference or the reference's unstable sort may swap members in and out of the top-k)
+        full = ref.all_scores(Q[qi:qi + 1].permute(0, 2, 1), cand[qi].tolist())
+        kth = es[-1]
+        near = {p for p, v in zip(cand[qi].tolist(), full.tolist()) if abs(v - kth) <= 2 * atol}
+        assert (set(tp[qi].tolist()) ^ set(ep)) <= near, (set(tp[qi].tolist()) ^ set(ep), near)
 
 
 def test_rerank_edge_cases(ca):

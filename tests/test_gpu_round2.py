@@ -1,0 +1,310 @@
+"""GPU parity tests added in round 2: the batched driver's query-token mask (keep_nonzero), the retrieve driver, the
+packed doc table, the fused rank_forward entry point, doc-shard candidate filtering with GLOBAL strides, and the
+NaN / Inf contract.  Tolerances as in test_gpu_parity.py: fp32 |d| <= 1e-4, 16-bit inputs |d| <= 1e-3."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ATOL32 = 1e-4
+ATOL16 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import colbert_amd
+    return colbert_amd
+
+
+def nrm(gen, *shape):
+    return F.normalize(torch.randn(*shape, generator=gen), dim=-1)
+
+
+def _random_index(gen, ndocs, h, lo, hi, dtype=torch.float16):
+    doclens = torch.randint(lo, hi + 1, (ndocs,), generator=gen).tolist()
+    half = ndocs // 2
+    pdl = [doclens[:half], doclens[half:]]
+    parts = [nrm(gen, sum(d), h).to(dtype) for d in pdl]
+    return parts, pdl
+
+
+def _holey_mask(gen, nq, Lq):
+    """q_active_padding as tokenize_seqs emits it (tokenizers.py:36): zeros for punctuation / [SEP] in the MIDDLE of the
+    sequence and for the padding tail; one query keeps everything, one keeps a single token."""
+    m = (torch.rand(nq, Lq, generator=gen) > 0.3).long()
+    m[:, 0] = 1
+    for qi in range(nq):
+        tail = int(torch.randint(0, Lq // 2 + 1, (1,), generator=gen))
+        if tail:
+            m[qi, Lq - tail:] = 0
+    m[0] = 1
+    if nq > 1:
+        m[1] = 0
+        m[1, Lq // 2] = 1
+    return m
+
+
+# ------------------------------------------------------------------------------------------------------
+# q_mask: dense_server_client.py:45 + training_utils.py:48-53 for a batch, without compacting Q
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(ndocs=300, h=128, lo=1, hi=180, nq=6, ncand=97, Lq=32, dtype=torch.float32),      # f32 MFMA, two column blocks
+    dict(ndocs=120, h=128, lo=1, hi=60, nq=4, ncand=64, Lq=12, dtype=torch.float32),       # one column block
+    dict(ndocs=64, h=128, lo=8, hi=8, nq=4, ncand=64, Lq=8, dtype=torch.float32),          # half-tile kernel
+    dict(ndocs=64, h=128, lo=8, hi=12, nq=4, ncand=64, Lq=32, dtype=torch.float32),        # half-tile kernel, two blocks
+    dict(ndocs=200, h=128, lo=1, hi=90, nq=4, ncand=50, Lq=32, dtype=torch.float16),       # reference storage dtype
+    dict(ndocs=200, h=128, lo=1, hi=90, nq=4, ncand=50, Lq=32, dtype=torch.bfloat16),
+    dict(ndocs=14, h=768, lo=100, hi=256, nq=3, ncand=14, Lq=32, dtype=torch.bfloat16, qdtype=torch.bfloat16),  # LDS-query kernel
+    dict(ndocs=30, h=256, lo=1, hi=70, nq=3, ncand=30, Lq=32, dtype=torch.float32),
+    dict(ndocs=40, h=24, lo=1, hi=40, nq=3, ncand=30, Lq=12, dtype=torch.float32),         # generic kernel
+    dict(ndocs=60, h=128, lo=1, hi=90, nq=3, ncand=50, Lq=40, dtype=torch.float32),        # Lq > 32: two query slices
+])
+def test_q_mask_equals_keep_nonzero(ca, cfg):
+    from oracle.maxsim_oracle import RefRanker, keep_nonzero
+    gen = torch.Generator().manual_seed(1000 + cfg["ndocs"] + cfg["h"] + cfg["Lq"])
+    parts, pdl = _random_index(gen, cfg["ndocs"], cfg["h"], cfg["lo"], cfg["hi"], cfg["dtype"])
+    ref = RefRanker(parts, pdl, dim=cfg["h"], index_dtype=cfg["dtype"])
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=cfg["h"], index_dtype=cfg["dtype"])
+    Q = nrm(gen, cfg["nq"], cfg["Lq"], cfg["h"])
+    Qdev = Q.to(cfg["qdtype"]) if "qdtype" in cfg else Q
+    Q = Qdev.float()
+    mask = _holey_mask(gen, cfg["nq"], cfg["Lq"])
+    cand = torch.stack([torch.randperm(cfg["ndocs"], generator=gen)[:cfg["ncand"]] for _ in range(cfg["nq"])])
+    atol = ATOL32
+    sc = r.score_candidates(Qdev, cand, q_mask=mask).cpu()
+    tp, ts = r.rerank_batch(Qdev, cand, depth=10, q_mask=mask)
+    for qi in range(cfg["nq"]):
+        q_live, _ = keep_nonzero(Q[qi], mask[qi])                               # what the reference hands to search()
+        exp = ref.all_scores(q_live.unsqueeze(0).permute(0, 2, 1), cand[qi].tolist())
+        torch.testing.assert_close(sc[qi], exp, rtol=0, atol=atol)
+        ep, es = ref.rank_forward(q_live.unsqueeze(0).permute(0, 2, 1), cand[qi].tolist(), depth=10)
+        np.testing.assert_allclose(ts[qi].cpu().numpy(), np.array(es), rtol=0, atol=atol)
+    # q_len and q_mask combine (token scored iff below q_len AND kept), and a float / bool mask means the same
+    q_len = torch.tensor([max(1, cfg["Lq"] - 3)] * cfg["nq"], dtype=torch.int32)
+    sc2 = r.score_candidates(Qdev, cand, q_len=q_len, q_mask=mask.bool()).cpu()
+    m2 = mask.clone()
+    m2[:, cfg["Lq"] - 3:] = 0
+    sc3 = r.score_candidates(Qdev, cand, q_mask=m2.float()).cpu()
+    assert torch.equal(sc2, sc3)
+    # an all-ones mask is bit-identical to no mask
+    assert torch.equal(r.score_candidates(Qdev, cand, q_mask=torch.ones_like(mask)).cpu(), r.score_candidates(Qdev, cand).cpu())
+
+
+def test_retrieve_batch_equals_reference_loop(ca):
+    """colbert_amd.retrieve_batch against the reference's per-query loop (dense_server_client.py:44-48 ->
+    faiss_indexers.py:224-235 -> colbert_ranker.py:176-229, 75-137) on the oracle, with a toy exact-search ANN."""
+    from oracle.maxsim_oracle import RefRanker, keep_nonzero
+    gen = torch.Generator().manual_seed(321)
+    doclens = torch.randint(1, 60, (300,), generator=gen).tolist()
+    parts = [nrm(gen, sum(doclens), 128).half()]
+    ref = RefRanker(parts, [doclens], dim=128)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=[doclens], dim=128)
+    bs, Lq, depth = 5, 32, 8
+    Q = nrm(gen, bs, Lq, 128)
+    mask = _holey_mask(gen, bs, Lq)
+    index_f = parts[0].float()
+    emb2pid = torch.repeat_interleave(torch.arange(len(doclens)), torch.tensor(doclens))     # colbert_ranker.py:163-174
+
+    def ann(q_live, faiss_depth):                              # stands in for faiss_index.search (third-party)
+        return (q_live.float().cpu() @ index_f.T).topk(faiss_depth, dim=-1).indices
+
+    out = ca.retrieve_batch(r, Q, mask, topk=10, ann_search=ann, faiss_depth=depth)
+    # the other calling form: ids for every token (dead rows hold garbage that must be ignored)
+    all_ids = (Q.reshape(-1, 128) @ index_f.T).topk(depth, dim=-1).indices.view(bs, Lq, depth)
+    out2 = ca.retrieve_batch(r, Q, mask, topk=10, embedding_ids=all_ids)
+    assert len(out) == bs
+    for qi in range(bs):
+        q_live, _ = keep_nonzero(Q[qi], mask[qi])                                            # dense_server_client.py:45
+        ids = ann(q_live, depth)                                                              # colbert_ranker.py:183-210
+        pids = sorted(set(emb2pid[ids.reshape(-1)].tolist()))                                 # :212-229 (set -> any order)
+        ep, es = ref.rank_forward(q_live.unsqueeze(0).permute(0, 2, 1), pids, depth=10)      # faiss_indexers.py:232-234
+        for got in (out[qi], out2[qi]):
+            assert len(got[0]) == len(ep) == len(got[1])
+            np.testing.assert_allclose(np.array(got[1]), np.array(es), rtol=0, atol=ATOL32)
+            assert got[0] == ep
+
+
+# ------------------------------------------------------------------------------------------------------
+# packed doc table, the fused rank_forward entry, C-ABI level
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("h,dtype", [(128, torch.float32), (128, torch.float16), (768, torch.bfloat16), (24, torch.float32)])
+def test_doc_table_is_bit_identical_to_the_three_arrays(ca, h, dtype):
+    gen = torch.Generator().manual_seed(7 + h)
+    parts, pdl = _random_index(gen, 150, h, 0, 120, dtype)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=h, index_dtype=dtype)
+    Q = nrm(gen, 4, 32, h).cuda()
+    cand = torch.stack([torch.randperm(150, generator=gen)[:90] for _ in range(4)]).cuda()
+    cand[0, 3], cand[1, 7] = -1, 10 ** 9                                 # padding slots
+    with_table = r.score_candidates(Q, cand)
+    assert r._iv.doc_table is not None
+    tbl = r.d_doc_table.view(torch.int64).view(-1, 2).cpu()
+    assert torch.equal(tbl[:, 0], r.d_offsets.cpu())
+    assert torch.equal(tbl[:, 1] & 0xffffffff, r.d_doclens.cpu().long()) and torch.equal(tbl[:, 1] >> 32, r.d_pad_len.cpu().long())
+    L = ca._lib.lib
+    plain = torch.empty_like(with_table)
+    rc = L.maxsim_rerank(r.tensor.data_ptr(), r._iv.index_dtype, r.num_embeddings, r.d_offsets.data_ptr(),
+                         r.d_doclens.data_ptr(), r.d_pad_len.data_ptr(), r.n_docs, Q.data_ptr(), 0, None, cand.data_ptr(),
+                         4, 90, 32, h, plain.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert torch.equal(plain, with_table)
+
+
+def test_rank_forward_input_forms_and_threads(ca, golden):
+    """rank_forward through the one-call entry (pinned in/out buffers): python list, CPU tensor and device tensor pids
+    give the same lists; concurrent host threads have their own workspaces."""
+    import threading
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(17)
+    parts, pdl = _random_index(gen, 500, 128, 1, 180, torch.float16)
+    ref = RefRanker(parts, pdl, dim=128)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=128)
+    q = nrm(gen, 32, 128)
+    Q = q.unsqueeze(0).permute(0, 2, 1)                      # [1, h, Lq], a permuted view as faiss_indexers.py:232-233
+    pids = torch.randperm(500, generator=gen)[:333].tolist()
+    ep, es = ref.rank_forward(Q, pids, depth=100)
+    for form in (pids, torch.tensor(pids), torch.tensor(pids).cuda(), np.array(pids).tolist()):
+        for Qin in (Q, Q.cuda(), Q.contiguous().cuda().half()):
+            gp, gs = r.rank_forward(Qin, form, depth=100)
+            atol = ATOL32 if Qin.dtype == torch.float32 else 5e-3
+            np.testing.assert_allclose(np.array(gs), np.array(es), rtol=0, atol=atol)
+            if Qin.dtype == torch.float32:
+                assert gp == ep
+    assert r.rank_forward(Q, pids[:3], depth=10)[0] == ref.rank_forward(Q, pids[:3], depth=10)[0]     # depth > n
+    with pytest.raises(AssertionError):
+        r.rank_forward(Q, [], depth=10)
+    errors = []
+
+    def worker(tid):
+        g2 = torch.Generator().manual_seed(100 + tid)
+        for it in range(20):
+            pp = torch.randperm(500, generator=g2)[:200].tolist()
+            a = r.rank_forward(Q, pp, depth=20)
+            b = ref.rank_forward(Q, pp, depth=20)
+            if a[0] != b[0] or max(abs(x - y) for x, y in zip(a[1], b[1])) > ATOL32:
+                errors.append((tid, it))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors
+
+
+# ------------------------------------------------------------------------------------------------------
+# doc-sharded path on the GPU: shard filter kernel, global strides
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nq,ncand", [(1, 1), (3, 64), (5, 1000), (2, 257), (4, 16384)])
+def test_shard_candidates_kernel_equals_stable_partition(ca, nq, ncand):
+    from colbert_amd.sharded import shard_candidates
+    gen = torch.Generator().manual_seed(nq * 7 + ncand)
+    cand = torch.randint(0, 4000, (nq, ncand), generator=gen)
+    cand[0, 0] = -1
+    for lo, hi in ((0, 4000), (1000, 2000), (3999, 4000), (5000, 6000), (100, 100)):
+        loc_c, gp_c = shard_candidates(cand, lo, hi)                     # torch reference (CPU ranks)
+        loc_g, gp_g = shard_candidates(cand.cuda(), lo, hi)              # maxsim_shard_candidates
+        assert torch.equal(loc_g.cpu(), loc_c) and torch.equal(gp_g.cpu(), gp_c)
+    # in place + counts through the C ABI
+    c = cand.cuda().clone()
+    cnt = torch.empty(nq, dtype=torch.int32, device="cuda")
+    rc = ca._lib.lib.maxsim_shard_candidates(c.data_ptr(), nq, ncand, 1000, 2000, c.data_ptr(), None, cnt.data_ptr(),
+                                             torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    exp_loc, _ = shard_candidates(cand, 1000, 2000)
+    assert torch.equal(c.cpu(), exp_loc) and torch.equal(cnt.cpu().long(), (exp_loc >= 0).sum(1))
+
+
+def test_sharded_shard_scores_equal_the_unsharded_reference(ca):
+    """Each shard of a ragged index, bucketed by the GLOBAL strides, scores its docs exactly as ONE reference ranker over
+    the whole index does -- including the 'negative' query whose score is the zero-padding floor alone
+    (colbert_ranker.py:90,108-109); bucketed by its own percentiles it does not."""
+    from colbert_amd.sharded import ShardedRanker, merge_gathered, shard_range
+    from colbert_amd.ranker import reference_strides
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(77)
+    ndocs, h, world = 400, 128, 2
+    doclens = torch.cat([torch.randint(1, 40, (ndocs // 2,), generator=gen), torch.randint(30, 181, (ndocs // 2,), generator=gen)]).tolist()
+    emb = torch.randn(sum(doclens), h, generator=gen) * 0.05
+    emb[:, 0] += 1.0
+    emb = F.normalize(emb, dim=-1).half()
+    whole = RefRanker([emb], [doclens], dim=h)
+    Q = nrm(gen, 3, 32, h)
+    Q[2] = 0.0
+    Q[2, :, 0] = -1.0
+    cand = torch.stack([torch.randperm(ndocs, generator=gen)[:150] for _ in range(3)])
+    # make sure the negative query meets docs whose length EQUALS a stride (no padding, hence no floor) under the global
+    # strides and under the second shard's own percentiles
+    own1 = reference_strides(torch.tensor(doclens[ndocs // 2:]))
+    special = [p for p in range(ndocs) if doclens[p] in whole.strides or (p >= ndocs // 2 and doclens[p] in own1)][:40]
+    rest = [p for p in cand[2].tolist() if p not in special]
+    cand[2] = torch.tensor((special + rest)[:150])
+    exp = torch.stack([whole.all_scores(Q[qi:qi + 1].permute(0, 2, 1), cand[qi].tolist()) for qi in range(3)])
+    offs = [0]
+    for d in doclens:
+        offs.append(offs[-1] + d)
+    gstr = reference_strides(torch.tensor(doclens))
+    assert gstr == whole.strides
+    tops, tops_own = [], []
+    for rank in range(world):
+        lo, hi = shard_range(ndocs, rank, world)
+        kw = dict(parts=[emb[offs[lo]:offs[hi]]], parts_doclens=[doclens[lo:hi]], dim=h)
+        r = ca.ColbertRanker(strides=gstr, **kw)
+        r_own = ca.ColbertRanker(**kw)
+        assert r.strides == whole.strides and r_own.strides != whole.strides
+        assert torch.equal(r.d_pad_len.cpu().long(), whole.bucket_strides(list(range(lo, hi))))
+        tops.append(ShardedRanker(r, lo, hi).local_topk(Q, cand.cuda(), 150))
+        tops_own.append(ShardedRanker(r_own, lo, hi).local_topk(Q, cand.cuda(), 150))
+    def merged(t):
+        gs = torch.stack([x[1] for x in t])
+        gp = torch.stack([x[0] for x in t])
+        return merge_gathered(gs, gp, 150, r.topk)
+    mp, ms = merged(tops)
+    es, ei = torch.sort(exp, dim=1, descending=True, stable=True)
+    np.testing.assert_allclose(ms.cpu().numpy(), es.numpy(), rtol=0, atol=ATOL32)
+    lookup = [dict(zip(cand[qi].tolist(), exp[qi].tolist())) for qi in range(3)]
+    for qi in range(3):
+        assert sorted(mp[qi].tolist()) == sorted(cand[qi].tolist())
+        for p, v in zip(mp[qi].tolist(), ms[qi].tolist()):
+            assert abs(lookup[qi][p] - v) <= ATOL32
+    assert bool((exp[2] == 0).any()) and bool((exp[2] < -1).any())      # the floor decides: both kinds are present
+    _, ms_own = merged(tops_own)
+    assert float((ms_own.cpu() - es).abs().max()) > 1.0                 # per-shard percentiles would change scores
+
+
+# ------------------------------------------------------------------------------------------------------
+# NaN / Inf contract (DESIGN.md "Non-finite inputs")
+# ------------------------------------------------------------------------------------------------------
+def test_non_finite_inputs_contract(ca):
+    """The reference's torch.max / sum propagate NaN (BaseModel.py:44-45).  The encoder emits L2-normalised, finite rows
+    (BaseModel.py:26), so finite inputs are the contract; what the kernels do beyond it is pinned here:
+      * +-Inf similarities behave as in torch wherever torch's result is not NaN (max picks +inf, the sum is +-inf);
+      * a NaN similarity is IGNORED by the running max (v_max_f32 = IEEE maxNum), where torch returns NaN: a doc whose
+        every other token is finite gets the max over those tokens; a query token whose similarities are all NaN
+        contributes -inf, 0 with the padding floor."""
+    from oracle.maxsim_oracle import ref_score
+    gen = torch.Generator().manual_seed(3)
+    doclens = [20, 20, 20, 20, 20, 20]
+    emb = nrm(gen, sum(doclens), 128)
+    emb[5, 3] = float("inf")            # doc 0: one +inf component
+    emb[25, 7] = float("-inf")          # doc 1: one -inf component
+    emb[45, 9] = float("nan")           # doc 2: one NaN component in one token
+    Q = nrm(gen, 1, 32, 128).abs() + 0.01         # strictly positive components: inf * q is +-inf, never NaN
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=128, index_dtype=torch.float32)
+    sc = r.score_candidates(Q, torch.arange(6).view(1, 6)).cpu()[0]
+    D = emb.view(6, 20, 128)
+    exp = ref_score(Q, D, torch.ones(1, 32), torch.ones(6, 20))[0]
+    assert sc[0] == float("inf") and exp[0] == float("inf")
+    # -inf token: torch's max ignores it too (other tokens are larger): finite, equal
+    assert abs(sc[1] - exp[1]) <= ATOL32
+    assert torch.isnan(exp[2])                                   # torch propagates
+    alt = emb.clone()
+    alt[45] = alt[44]                                            # the kernel's answer: the NaN token never wins a max
+    exp2 = ref_score(Q, alt.view(6, 20, 128)[2:3], torch.ones(1, 32), torch.ones(1, 20))[0, 0]
+    assert torch.isfinite(sc[2]) and abs(sc[2] - exp2) <= ATOL32
+    np.testing.assert_allclose(sc[3:].numpy(), exp[3:].numpy(), rtol=0, atol=ATOL32)
+    # the dense operator seam behaves the same way
+    out = ca.score(Q.cuda(), D.cuda(), torch.ones(1, 32).cuda(), torch.ones(6, 20).cuda()).cpu()[0]
+    assert out[0] == float("inf") and torch.isfinite(out[2]) and abs(out[1] - exp[1]) <= ATOL32

@@ -29,6 +29,22 @@ def cpu_topk(scores, pids, k):
     return p[:, :k].contiguous(), es[:, :k].contiguous()
 
 
+def same_ranking(got_p, got_s, exp_scores, cand, k, atol=1e-5):
+    """Top-k equality modulo the order of tied scores (the reference's sort is unstable, colbert_ranker.py:128): the score
+    lists are equal, and every returned pid carries the score the whole-index oracle gives THAT pid."""
+    _, es = cpu_topk(exp_scores, cand, k)
+    if not torch.allclose(got_s, es, atol=atol, rtol=0):
+        return False
+    for qi in range(cand.size(0)):
+        if len(set(got_p[qi].tolist())) != got_p.size(1):
+            return False
+        for p, sc in zip(got_p[qi].tolist(), got_s[qi].tolist()):
+            pos = (cand[qi] == p).nonzero()
+            if len(pos) == 0 or abs(float(exp_scores[qi, pos[0, 0]]) - sc) > atol:
+                return False
+    return True
+
+
 def make_scorer(ref):
     def scorer(Q, cand_local, q_len=None):
         out = torch.full(cand_local.shape, NEG_INF)
@@ -41,12 +57,21 @@ def make_scorer(ref):
     return scorer
 
 
-def build_world(seed=0, ndocs=40, h=16):
+def build_world(seed=0, ndocs=48, h=16):
+    """A ragged index whose two halves have DIFFERENT length distributions (short docs first, long docs last), so the
+    percentile strides of a shard differ from those of the whole index, and token embeddings that all lean towards
+    +e0, so the query -e0 has a negative similarity with every token: its score is decided by the reference's
+    zero-padding floor alone (colbert_ranker.py:90,108-109) -- i.e. by which strides the docs were bucketed with."""
     gen = torch.Generator().manual_seed(seed)
-    doclens = torch.randint(1, 20, (ndocs,), generator=gen).tolist()
-    emb = F.normalize(torch.randn(sum(doclens), h, generator=gen), dim=-1).half()
+    half = ndocs // 2
+    doclens = torch.cat([torch.randint(1, 9, (half,), generator=gen), torch.randint(6, 20, (ndocs - half,), generator=gen)]).tolist()
+    emb = torch.randn(sum(doclens), h, generator=gen) * 0.3
+    emb[:, 0] += 1.0
+    emb = F.normalize(emb, dim=-1).half()
     Q = F.normalize(torch.randn(3, 6, h, generator=gen), dim=-1)
-    cand = torch.stack([torch.randperm(ndocs, generator=gen)[:17] for _ in range(3)])
+    Q[2] = 0.0
+    Q[2, :, 0] = -1.0                      # the "negative" query
+    cand = torch.stack([torch.randperm(ndocs, generator=gen)[:29] for _ in range(3)])
     return doclens, emb, Q, cand
 
 
@@ -55,34 +80,59 @@ def _worker(rank, world, port, ret):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        from colbert_amd.sharded import ShardedRanker, shard_range
+        from colbert_amd.sharded import ShardedRanker, global_strides, shard_range
         doclens, emb, Q, cand = build_world()
         ndocs = len(doclens)
         lo, hi = shard_range(ndocs, rank, world)
         offs = [0]
         for d in doclens:
             offs.append(offs[-1] + d)
-        # NOTE: each shard computes its own length-bucket strides (as a reference-built per-shard index would)
+        # expected: ONE reference ranker over the WHOLE index (what an unsharded deployment returns)
+        whole = RefRanker([emb], [doclens], dim=emb.size(1))
+        exp = torch.stack([whole.all_scores(Q[qi].unsqueeze(0).permute(0, 2, 1), cand[qi].tolist()) for qi in range(Q.size(0))])
+        K = cand.size(1)                    # the whole list: every candidate's score is checked, not only the best five
+        # the shard: an oracle ranker over the local docs, bucketed by the GLOBAL strides
         local = RefRanker([emb[offs[lo]:offs[hi]]], [doclens[lo:hi]], dim=emb.size(1))
+        own_strides = list(local.strides)
+        gs = global_strides(doclens[lo:hi])
+        checks = {'global_strides': gs == whole.strides, 'not_vacuous': own_strides != whole.strides}
+        local.strides = gs
+        local.views = local._create_views(local.tensor)
         sh = ShardedRanker(object(), lo, hi, score_fn=make_scorer(local), topk_fn=cpu_topk)
+        top_p, top_s = sh.rerank_batch(Q, cand, depth=K)
+        checks['sharded_eq_whole'] = same_ranking(top_p, top_s, exp, cand, K)
         top_p, top_s = sh.rerank_batch(Q, cand, depth=5)
-        # expected: per query, union of per-shard scores
-        exp = torch.full(cand.shape, NEG_INF)
-        for r in range(world):
-            l2, h2 = shard_range(ndocs, r, world)
-            ref_r = RefRanker([emb[offs[l2]:offs[h2]]], [doclens[l2:h2]], dim=emb.size(1))
-            sc = make_scorer(ref_r)(Q, torch.where((cand >= l2) & (cand < h2), cand - l2, torch.full_like(cand, -1)))
-            exp = torch.maximum(exp, sc)
-        ep, es = cpu_topk(exp, cand, 5)
-        ok = torch.equal(top_s, es) and torch.equal(top_p, ep)
+        checks['sharded_eq_whole_top5'] = same_ranking(top_p, top_s, exp, cand, 5)
+        # ... and bucketing each shard by its OWN percentiles (round 1's behaviour) gives different scores here
+        local_own = RefRanker([emb[offs[lo]:offs[hi]]], [doclens[lo:hi]], dim=emb.size(1))
+        sh_own = ShardedRanker(object(), lo, hi, score_fn=make_scorer(local_own), topk_fn=cpu_topk)
+        own_p, own_s = sh_own.rerank_batch(Q, cand, depth=K)
+        checks['own_strides_differ'] = not same_ranking(own_p, own_s, exp, cand, K, atol=1e-3)
+        # q_mask / q_len travel through the sharded path
+        qm = torch.ones(Q.shape[:2], dtype=torch.long)
+        qm[:, 1] = 0
+        qm[0, 4] = 0
+        def masked_scorer(Qb, cl, q_mask=None, q_len=None):
+            out = torch.full(cl.shape, NEG_INF)
+            for qi in range(Qb.size(0)):
+                okc = (cl[qi] >= 0).nonzero().flatten()
+                if len(okc):
+                    q = Qb[qi][q_mask[qi].bool()]
+                    out[qi, okc] = local.all_scores(q.unsqueeze(0).permute(0, 2, 1), cl[qi, okc].tolist())
+            return out
+        shm = ShardedRanker(object(), lo, hi, score_fn=masked_scorer, topk_fn=cpu_topk)
+        mp_, ms_ = shm.rerank_batch(Q, cand, depth=K, q_mask=qm)
+        expm = torch.stack([whole.all_scores(Q[qi][qm[qi].bool()].unsqueeze(0).permute(0, 2, 1), cand[qi].tolist())
+                            for qi in range(Q.size(0))])
+        checks['q_mask'] = same_ranking(mp_, ms_, expm, cand, K)
         # the pipelined form bench.py uses: local top-k, then the exchange as a handle (synchronous on CPU ranks);
         # two batches in flight, resolved in issue order
         h1 = sh.exchange_async(*sh.local_topk(Q, cand, 5), 5)
         h2 = sh.exchange_async(*sh.local_topk(Q, cand.flip(1), 5), 5)
         p1, s1 = h1.result()
         p2, s2 = h2.result()
-        ok = ok and torch.equal(s1, es) and torch.equal(p1, ep) and torch.equal(s2, es)
-        ret[rank] = bool(ok)
+        checks['pipelined'] = same_ranking(p1, s1, exp, cand, 5) and same_ranking(p2, s2, exp, cand, 5)
+        ret[rank] = sorted(k for k, v in checks.items() if not v)
     finally:
         dist.destroy_process_group()
 
@@ -94,7 +144,27 @@ def test_doc_sharded_rerank_world2():
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: True, 1: True}
+    assert dict(ret) == {0: [], 1: []}          # per rank: the names of the failed checks
+
+
+def test_strides_from_histogram_equal_kthvalue():
+    from colbert_amd.ranker import reference_strides, strides_from_histogram
+    g = torch.Generator().manual_seed(5)
+    for n, hi in [(4, 3), (5, 9), (97, 180), (1000, 12), (1001, 300), (64, 1)]:
+        dl = torch.randint(0 if hi > 1 else 1, hi + 1, (n,), generator=g)
+        if int(dl.max()) == 0:
+            dl[0] = 1
+        assert strides_from_histogram(torch.bincount(dl)) == reference_strides(dl), (n, hi)
+    with pytest.raises(RuntimeError):
+        strides_from_histogram(torch.bincount(torch.tensor([1, 2, 3])))      # N < 4: kthvalue(0), as the reference
+
+
+def test_shard_candidates_cpu_partition_is_stable():
+    from colbert_amd.sharded import shard_candidates
+    c = torch.tensor([[0, 5, 9, 3, 4], [4, 4, 2, 8, 5]])
+    loc, gp = shard_candidates(c, 3, 6)
+    assert loc.tolist() == [[2, 0, 1, -1, -1], [1, 1, 2, -1, -1]]
+    assert gp.tolist() == [[5, 3, 4, -1, -1], [4, 4, 5, -1, -1]]
 
 
 def test_shard_range_and_localize():
