@@ -16,7 +16,7 @@ OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 
 SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk",
            "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
-           "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_doc_table_bytes",
+           "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_rank_forward_workspace_bytes", "maxsim_doc_table_bytes",
            "maxsim_build_doc_table", "maxsim_shard_candidates")
 
 
@@ -63,7 +63,9 @@ def _load():
     lib.maxsim_rerank_ex.restype = i32
     lib.maxsim_rerank_ex.argtypes = [ivp, vp, i32, vp, vp, vp, i32, i32, i32, vp, vp]
     lib.maxsim_rank_forward.restype = i32
-    lib.maxsim_rank_forward.argtypes = [ivp, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32, vp]
+    lib.maxsim_rank_forward.argtypes = [ivp, vp, i32, i32, vp, i32, i32, vp, vp, vp, vp, i32, vp]
+    lib.maxsim_rank_forward_workspace_bytes.restype = i64
+    lib.maxsim_rank_forward_workspace_bytes.argtypes = [i32]
     lib.maxsim_doc_table_bytes.restype = i64
     lib.maxsim_doc_table_bytes.argtypes = [i64]
     lib.maxsim_build_doc_table.restype = i32

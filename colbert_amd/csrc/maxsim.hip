@@ -194,9 +194,12 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   return check_launch();
 }
 
+// ep != NULL: the caller wants the fused top-k epilogue; *fused tells whether the launch carried it (only the small-launch
+// forms of the h = 128 kernel do) -- if not, the caller ranks the score rows with maxsim_topk.
 static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, const int32_t* q_len,
                        const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
-                       hipStream_t st) {
+                       hipStream_t st, const Epilogue* ep = nullptr, bool* fused = nullptr) {
+  if (fused) *fused = false;
   const int h = iv.h, index_dtype = iv.index_dtype;
   const int64_t n_tokens = iv.n_tokens, n_docs = iv.n_docs;
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
@@ -228,6 +231,15 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
   const bool aligned = (((uintptr_t)Q | (uintptr_t)iv.index) & 15) == 0;  // the streaming kernels move 16-byte pieces
   const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
   if (h == 128 && stream_ok) {
+    if (Lq <= 32) {  // small launches: docs split over several waves, top-k fused into the last workgroup
+      if (ep) p.ep = *ep;
+      const int rc = launch_stream_small(p, index_dtype, ep != nullptr, st);
+      p.ep = Epilogue{};
+      if (rc != MAXSIM_ERANGE) {
+        if (fused) *fused = ep != nullptr && rc == MAXSIM_OK;
+        return rc;
+      }
+    }
     return for_query_slices(p, [&] { return launch_stream_rerank(p, index_dtype, st); });
   }
   const int esz = (index_dtype == MAXSIM_F32 || index_dtype >= MAXSIM_F32_FAST) ? 4 : 2;
@@ -292,6 +304,20 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
   if (ncand > 16384) return MAXSIM_ERANGE;
   if (nq == 0) return MAXSIM_OK;
   if (!scores || !out_scores || !out_pids) return MAXSIM_EINVAL;
+  if (ncand <= 2048) {  // short lists: the register / lane-exchange workgroup sort (maxsim_topk.h)
+    const int R = ncand <= 256 ? 1 : (ncand <= 512 ? 2 : (ncand <= 1024 ? 4 : 8));
+    if (k <= 256 * R) {
+      const dim3 grid((unsigned)nq), block(256);
+      hipStream_t st = (hipStream_t)stream;
+      switch (R) {
+        case 1: hipLaunchKernelGGL(k_topk_small<1>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
+        case 2: hipLaunchKernelGGL(k_topk_small<2>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
+        case 4: hipLaunchKernelGGL(k_topk_small<4>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
+        default: hipLaunchKernelGGL(k_topk_small<8>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
+      }
+      return check_launch();
+    }
+  }
   int P = 2;
   while (P < ncand) P <<= 1;
   const int ldsb = P * 8;
@@ -303,18 +329,50 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
   return check_launch();
 }
 
+int64_t maxsim_rank_forward_workspace_bytes(int n) { return n > 0 ? (int64_t)n * 4 + 64 : 64; }
+
 int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype, int Lq, const int64_t* pids, int n,
-                        int depth, float* scores_ws, int64_t* out_pids, float* out_scores, int sync, void* stream) {
+                        int depth, void* workspace, int64_t* out_pids, float* out_scores, uint32_t* done_flag,
+                        int sync, void* stream) {
   if (!iv || n < 0 || depth < 1) return MAXSIM_EINVAL;
   if (n == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
   if (n > 16384) return MAXSIM_ERANGE;
-  if (!scores_ws || !out_pids || !out_scores) return MAXSIM_EINVAL;
-  int rc = rerank_impl(*iv, Q, q_dtype, nullptr, nullptr, pids, 1, n, Lq, scores_ws, (hipStream_t)stream);
+  if (!workspace || ((uintptr_t)workspace & 15) != 0 || !out_pids || !out_scores) return MAXSIM_EINVAL;
+  // workspace: 64 bytes of counters (zero between calls) | n floats (the score vector, colbert_ranker.py:122)
+  int32_t* const counters = (int32_t*)workspace;
+  float* const scores = (float*)((char*)workspace + 64);
+  const int k = depth < n ? depth : n;
+  static std::atomic<uint32_t> tickets{0};
+  uint32_t ticket = ++tickets;
+  if (ticket == 0) ticket = ++tickets;
+  Epilogue ep{};
+  ep.counters = counters;
+  ep.out_s = out_scores;
+  ep.out_p = out_pids;
+  ep.done_flag = (sync && done_flag) ? done_flag : nullptr;
+  ep.ticket = ticket;
+  ep.k = k;
+  bool fused = false;
+  int rc = rerank_impl(*iv, Q, q_dtype, nullptr, nullptr, pids, 1, n, Lq, scores, (hipStream_t)stream, &ep, &fused);
   if (rc != MAXSIM_OK) return rc;
-  rc = maxsim_topk(scores_ws, pids, 1, n, depth < n ? depth : n, out_scores, out_pids, stream);  // colbert_ranker.py:128-130
-  if (rc != MAXSIM_OK) return rc;
-  if (sync && hipStreamSynchronize((hipStream_t)stream) != hipSuccess) return MAXSIM_ELAUNCH;
-  return MAXSIM_OK;
+  if (!fused) {
+    rc = maxsim_topk(scores, pids, 1, n, k, out_scores, out_pids, stream);  // colbert_ranker.py:128-130
+    if (rc != MAXSIM_OK) return rc;
+  }
+  if (!sync) return MAXSIM_OK;
+  if (fused && ep.done_flag) {
+    // the kernel's last workgroup stores `ticket` to the (host-visible) word after the top-k is written: spinning on it
+    // costs a fraction of a stream synchronisation.  Bounded: fall back to the runtime if it does not show up.
+    volatile uint32_t* f = done_flag;
+    for (int spins = 0; spins < (1 << 22); ++spins) {
+      if (*f == ticket) {
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return MAXSIM_OK;
+      }
+      __builtin_ia32_pause();
+    }
+  }
+  return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
 }
 
 int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,

@@ -22,6 +22,7 @@
 // There is no workgroup barrier: waves pace their own ring with counted s_waitcnt vmcnt.
 #pragma once
 #include "maxsim_common.h"
+#include "maxsim_sort.h"
 
 namespace maxsim {
 
@@ -370,35 +371,57 @@ struct Reducer16 {
 
 // Reducer for 32 query tokens held as TWO 16-column blocks of v_mfma_f32_16x16x4_f32 (QT_2X16): lane = query token
 // 16 cb + (lane & 15) of block cb x row quarter g = lane >> 4; sv[cb][4 b + v] = similarity with tile row 16 b + 4 g + v.
-struct Reducer2x16 {
+// SPLITK (small launches): a doc is streamed by several waves of the workgroup, each taking a slice of its tokens; when a
+// slice ends the wave parks its 32 per-query-token maxima in LDS (`part`: [doc ordinal][32] floats of this wave) instead
+// of finishing the score; the workgroup combines the slices after the stream (combine_split in the kernel).
+template <bool SPLITK>
+struct Reducer2x16T {
   float rmax0, rmax1, myscore;
   int jdoc;
+  float* part;
   __device__ __forceinline__ void init() {
     rmax0 = rmax1 = NEG_INF;
     myscore = 0.0f;
     jdoc = 0;
+    part = nullptr;
+  }
+  // per-query-token maximum of the finished doc (slice): lanes 0..15 = tokens 0..15, lanes 32..47 = tokens 16..31
+  // (lanes 16..31 / 48..63 mirror them)
+  __device__ __forceinline__ float token_max() const {
+    // quarters g, g + 2 (lane halves): one swap leaves block 0 in the lower half, block 1 in the upper half
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax0), __float_as_uint(rmax1), false, false);
+    float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    // quarters g, g + 1 (adjacent rows of 16 lanes)
+    const uint32_t xb = __float_as_uint(v);
+    const auto s16 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+    return fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+  }
+  // 0-floor, then the sum over the 32 query tokens as a fixed pairwise tree (the same tree whether the maxima come
+  // straight from the accumulators or from the parked slices: split and unsplit launches are bit-identical)
+  static __device__ __forceinline__ float floor_and_sum(float v, int floor0) {
+    if (floor0) v = fmaxf(v, 0.0f);
+    v += dpp_f32<0xB1>(v);
+    v += dpp_f32<0x4E>(v);
+    v += dpp_f32<0x141>(v);
+    v += dpp_f32<0x140>(v);  // 16-lane row sums: row 0 = query tokens 0..15, row 2 = tokens 16..31
+    return __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+           __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
   }
   __device__ __forceinline__ void finish_doc(const Cursor& C, int lane) {
-    float sc;
-    if (C.kind == 0) {
-      // quarters g, g + 2 (lane halves): one swap leaves block 0 in the lower half, block 1 in the upper half
-      const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(rmax0), __float_as_uint(rmax1), false, false);
-      float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
-      // quarters g, g + 1 (adjacent rows of 16 lanes)
-      const uint32_t xb = __float_as_uint(v);
-      const auto s16 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
-      v = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
-      if (C.floor0) v = fmaxf(v, 0.0f);
-      v += dpp_f32<0xB1>(v);
-      v += dpp_f32<0x4E>(v);
-      v += dpp_f32<0x141>(v);
-      v += dpp_f32<0x140>(v);  // 16-lane row sums: row 0 = query tokens 0..15, row 2 = tokens 16..31
-      sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
-           __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 32));
+    if constexpr (SPLITK) {
+      if (C.kind == 0) {
+        const float v = token_max();
+        if ((lane & 16) == 0) part[jdoc * 32 + (lane & 15) + ((lane >> 5) << 4)] = v;
+      }
     } else {
-      sc = C.kind == 1 ? 0.0f : NEG_INF;
+      float sc;
+      if (C.kind == 0) {
+        sc = floor_and_sum(token_max(), C.floor0);
+      } else {
+        sc = C.kind == 1 ? 0.0f : NEG_INF;
+      }
+      myscore = (lane == jdoc) ? sc : myscore;
     }
-    myscore = (lane == jdoc) ? sc : myscore;
     ++jdoc;
     rmax0 = rmax1 = NEG_INF;
   }
@@ -439,6 +462,7 @@ struct Reducer2x16 {
     }
   }
 };
+using Reducer2x16 = Reducer2x16T<false>;
 
 // Reduction state that also tracks WHERE each query token's maximum sits (training-form forward: the backward pass
 // routes gradients through the arg-max token, torch.max semantics = first maximal index).  Dense mode only.
@@ -503,9 +527,16 @@ struct ReducerArg {
 constexpr int QT_2X16 = 48;  // 32 query tokens as two 16-column blocks of v_mfma_f32_16x16x4_f32
 // QT = 16: at most 16 query tokens (e.g. the multi-view configs, dense.yaml q_view): fp32 index on
 // v_mfma_f32_16x16x4_f32 -- half the matrix-pipe time of the 32-column form, half the query registers.
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
+// Small launches (the reference's online call is ONE query x ~1000 candidates, faiss_indexers.py:234):
+//   SPLITK  a doc is streamed by p.split (2 or 4) waves of the workgroup, each a slice of its tokens -- with one wave per
+//           doc a 1000-candidate launch keeps half the SIMDs of the chip idle and every wave walks 6 tiles serially;
+//   EPI     the last workgroup of a query to finish also sorts the query's score row and writes the top-k (and a
+//           completion word the host can spin on): rank_forward is ONE launch instead of two.
+constexpr int SPLIT_MAX_DOCS = 8;  // docs per team of waves in a SPLITK launch (their parked maxima live in LDS)
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false, bool EPI = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
+  static_assert(!(SPLITK || EPI) || (MODE == MODE_RERANK && QT == QT_2X16 && WAVES == 4), "small-launch forms: two 16-column blocks only");
   static_assert(QT == 32 || (MODE == MODE_RERANK && ((QT == 16 && DT == MAXSIM_F32) ||
                                                      (QT == QT_2X16 && DT != F32S))),
                 "16-column forms: rerank only (the fp16-split fast mode keeps the 32x32x16 form: 1 % faster there)");
@@ -517,10 +548,20 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   const int wave = uni(threadIdx.x >> 6);
   const int qi = blockIdx.x / p.nchunk;
   const int chunk = blockIdx.x - qi * p.nchunk;
-  const int dpwv = p.dpw / WAVES;                 // docs per wave (<= 64)
-  const int c_begin = chunk * p.dpw + wave * dpwv;  // this wave's candidates: [c_begin, c_begin + ndoc)
+  // unsplit: every wave has its own docs.  SPLITK: `split` consecutive waves form a team that shares dpwv docs; wave
+  // `part` of the team streams the part-th slice of each doc (slices are whole 32-row tiles, cut as evenly as possible)
+  const int split = SPLITK ? p.split : 1;
+  const int team = SPLITK ? wave / split : wave, part = SPLITK ? wave - team * split : 0;
+  const int dpwv = SPLITK ? p.dpw / (WAVES / split) : p.dpw / WAVES;  // docs per wave / per team (<= 64; SPLITK: <= SPLIT_MAX_DOCS)
+  const int c_begin = chunk * p.dpw + team * dpwv;  // this wave's candidates: [c_begin, c_begin + ndoc)
   const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
-  const DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
+  DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
+  if constexpr (SPLITK) {
+    const int per = (((dl.len + 31) >> 5) + split - 1) / split * 32;  // rows per slice
+    const int start = min(dl.len, part * per);
+    dl.row0 += (uint32_t)start;
+    dl.len = min(dl.len - start, per);  // may be 0: the slice then parks -inf maxima (neutral)
+  }
   char* const wlds = lds + wave * (NT * TILE);
   const int r = lane & 31, hh = lane >> 5;
 
@@ -551,7 +592,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     }
     prev_issued = t.kind != 0;
   }
-  if (nissued == 0) {
+  if (!SPLITK && !EPI && nissued == 0) {  // (the small-launch forms meet at workgroup barriers below: no early exit)
     // nothing to stream: every slot of this wave is a padding slot (-inf) or an empty doc (0) -- e.g. the tail of a
     // doc-sharded candidate row (maxsim_shard_candidates).  Retire before the 16 KiB query tile is fetched.
     float* const srow0 = p.scores + (int64_t)qi * p.ncand + c_begin;
@@ -669,10 +710,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 
   Reducer red;
   Reducer16 red16;
-  Reducer2x16 red2;
+  Reducer2x16T<SPLITK> red2;
   red.init();
   red16.init();
   red2.init();
+  // SPLITK: this wave's parked maxima, [doc ordinal][32] floats, behind the waves' rings
+  float* const parked = (float*)(lds + WAVES * (NT * TILE));
+  if constexpr (SPLITK) red2.part = parked + wave * (SPLIT_MAX_DOCS * 32);
   int buf = 0;
 
   while (nconsumed < nissued) {
@@ -954,7 +998,28 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     ++nconsumed;
   }
   float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
-  if constexpr (QT == QT_2X16) {
+  if constexpr (SPLITK) {
+    red2.drain(C, dl, lane);
+    __syncthreads();  // every slice of the workgroup's docs is parked
+    if (part == 0) {
+      // combine the team's slices doc by doc: max over the slices, then exactly the unsplit wave's floor + sum tree
+      const int tok = (lane & 15) + ((lane >> 5) << 4);
+      float mine = 0.0f;
+      for (int j = 0; j < ndoc; ++j) {
+        const int fl = __builtin_amdgcn_readlane(dl.flags, j);
+        float sc;
+        if ((fl & 3) == 0) {
+          float v = NEG_INF;
+          for (int sp = 0; sp < split; ++sp) v = fmaxf(v, parked[(wave + sp) * (SPLIT_MAX_DOCS * 32) + j * 32 + tok]);
+          sc = Reducer2x16T<true>::floor_and_sum(v, fl >> 2);
+        } else {
+          sc = (fl & 3) == 1 ? 0.0f : NEG_INF;
+        }
+        mine = (lane == j) ? sc : mine;
+      }
+      if (lane < ndoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + mine;
+    }
+  } else if constexpr (QT == QT_2X16) {
     red2.drain(C, dl, lane);
     if (lane < red2.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red2.myscore;
   } else if constexpr (QT == 16) {
@@ -963,6 +1028,33 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   } else {
     red.drain(C, dl, lane);
     if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
+  }
+  if constexpr (EPI) {
+    // ---- fused top-k: the query's last workgroup to get here ranks the row (colbert_ranker.py:128-130) -------------
+    __shared__ int s_last;
+    __threadfence();  // this wave's scores are visible device-wide ...
+    __syncthreads();  // ... for all four waves
+    if (threadIdx.x == 0) s_last = atomicAdd(p.ep.counters + qi, 1) == p.nchunk - 1;
+    __syncthreads();
+    if (s_last) {
+      __threadfence();
+      const float* row = p.scores + (int64_t)qi * p.ncand;
+      const int64_t* prow = p.cand + (int64_t)qi * p.ncand;
+      float* const os = p.ep.out_s + (int64_t)qi * p.ep.k;
+      int64_t* const op = p.ep.out_p + (int64_t)qi * p.ep.k;
+      if (p.ncand <= 1024) wg_topk_row<4>(row, prow, p.ncand, p.ep.k, os, op, (uint64_t*)lds, (int)threadIdx.x);
+      else wg_topk_row<8>(row, prow, p.ncand, p.ep.k, os, op, (uint64_t*)lds, (int)threadIdx.x);
+      __threadfence_system();  // the top-k (possibly in pinned host memory) before the completion word
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        p.ep.counters[qi] = 0;  // leave the workspace zeroed for the next call
+        if (atomicAdd(p.ep.counters + p.nq, 1) == p.nq - 1) {  // last query of the launch
+          p.ep.counters[p.nq] = 0;
+          __threadfence_system();
+          if (p.ep.done_flag) __hip_atomic_store(p.ep.done_flag, p.ep.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
   }
 }
 

@@ -1,22 +1,23 @@
-// maxsim_topk.h -- per-query top-k (bitonic sort in LDS) and small utility kernels.
+// maxsim_topk.h -- per-query top-k and small utility kernels.
 #pragma once
 #include "maxsim_common.h"
+#include "maxsim_sort.h"
 
 namespace maxsim {
 
-// =============================================================================================
-// Per-query top-k: bitonic sort of (score, position) keys in LDS.  One workgroup per query.
-// key = orderable(score) << 32 | ~position  -> descending sort = score desc, position asc.
-// =============================================================================================
-__device__ __forceinline__ uint32_t orderable(float f) {
-  uint32_t u = __float_as_uint(f);
-  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float unorderable(uint32_t k) {
-  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-  return __uint_as_float(u);
+template <int R>
+__global__ void __launch_bounds__(256) k_topk_small(const float* __restrict__ scores, const int64_t* __restrict__ pids,
+                                                    int ncand, int k, float* __restrict__ out_s,
+                                                    int64_t* __restrict__ out_p) {
+  __shared__ uint64_t lds[256 * R];
+  const int q = blockIdx.x;
+  wg_topk_row<R>(scores + (int64_t)q * ncand, pids ? pids + (int64_t)q * ncand : nullptr, ncand, k,
+                 out_s + (int64_t)q * k, out_p + (int64_t)q * k, lds, threadIdx.x);
 }
 
+// =============================================================================================
+// Long lists (2048 < ncand <= 16384 = the reference's BSIZE): bitonic sort of the keys in LDS, one workgroup per query.
+// =============================================================================================
 __global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores, const int64_t* __restrict__ pids,
                                                int ncand, int k, int P, float* __restrict__ out_s,
                                                int64_t* __restrict__ out_p) {

@@ -55,15 +55,18 @@ def strides_from_histogram(hist):
 
 class _Workspace:
     """Per-thread buffers of ``rank_forward``: pinned host memory the GPU reads the pid list from and writes the top-k
-    to (no memcpy calls on the way in or out), and the device score vector."""
+    (and its completion word) to -- no memcpy calls on the way in or out -- and the device scratch of
+    ``maxsim_rank_forward`` (zeroed counters + the score vector)."""
 
     def __init__(self, device):
         self.pin_in = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
         self.pin_out_p = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
         self.pin_out_s = torch.empty(BSIZE, dtype=torch.float32).pin_memory()
-        self.scores = torch.empty(BSIZE, dtype=torch.float32, device=device)
+        self.pin_flag = torch.zeros(16, dtype=torch.int32).pin_memory()
+        self.scratch = torch.zeros(int(_lib.lib.maxsim_rank_forward_workspace_bytes(BSIZE)), dtype=torch.uint8, device=device)
         self.in_ptr, self.out_p_ptr, self.out_s_ptr = self.pin_in.data_ptr(), self.pin_out_p.data_ptr(), self.pin_out_s.data_ptr()
-        self.scores_ptr = self.scores.data_ptr()
+        self.flag_ptr, self.scratch_ptr = self.pin_flag.data_ptr(), self.scratch.data_ptr()
+        torch.cuda.synchronize(device)          # the zero fill has landed before the first launch on any stream
 
 
 class ColbertRanker:
@@ -295,10 +298,10 @@ class ColbertRanker:
         if torch.cuda.current_device() != dev.index and dev.index is not None:
             with torch.cuda.device(dev):
                 rc = _lib.lib.maxsim_rank_forward(ctypes.byref(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids,
-                                                  k, ws.scores_ptr, ws.out_p_ptr, ws.out_s_ptr, 1, _stream(dev))
+                                                  k, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr, 1, _stream(dev))
         else:
             rc = _lib.lib.maxsim_rank_forward(ctypes.byref(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids,
-                                              k, ws.scores_ptr, ws.out_p_ptr, ws.out_s_ptr, 1, _stream(dev))
+                                              k, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr, 1, _stream(dev))
         _lib.check(rc, "maxsim_rank_forward")
         return ws.pin_out_p[:k].tolist(), ws.pin_out_s[:k].tolist()
 

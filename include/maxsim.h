@@ -206,18 +206,28 @@ int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, co
 /*
  * One ColbertRanker.rank_forward (colbert_ranker.py:75-137) in one call: rerank of ONE query against n candidate
  * pids followed by the descending top-`depth` -- the reference's online call (faiss_indexers.py:234), where per-call
- * host overhead, not bandwidth, dominates.  Both kernels are enqueued back to back on `stream`.
+ * host overhead and launch latency, not bandwidth, dominate.  For h == 128, Lq <= 32, n <= 2048 and an F32 / F16 / BF16
+ * index this is ONE kernel launch: docs are split over several waves when the launch is small, and the last workgroup
+ * to finish sorts the score vector and writes the top-k.  Other shapes take two launches (rerank, then top-k).
  *   Q          [Lq, h] token-major, element type q_dtype (the shim undoes the reference's [1,h,Lq] permute)
  *   pids       [n] int64, any memory the GPU can read: device memory, or PINNED host memory (hipHostMalloc /
  *              torch pin_memory), which saves the H2D copy call
- *   scores_ws  [n] float32 device scratch (the full score vector, colbert_ranker.py:122, is left there)
- *   out_pids   [k] int64 and out_scores [k] float32, k = min(depth, n): device memory or pinned host memory (the top-k
- *              kernel then writes the result straight to the host; no D2H copy call)
- *   sync       != 0: hipStreamSynchronize(stream) before returning (results are then visible to the host)
+ *   workspace  device scratch of maxsim_rank_forward_workspace_bytes(n) bytes, 16-byte aligned; its first 64 bytes
+ *              must be ZERO before the first call and are left zero by every call (counters of the fused epilogue);
+ *              the n floats that follow receive the full score vector (colbert_ranker.py:122).  One workspace serves
+ *              one call at a time.
+ *   out_pids   [k] int64 and out_scores [k] float32, k = min(depth, n): device memory or pinned host memory (the kernel
+ *              then writes the result straight to the host; no D2H copy call)
+ *   done_flag  NULL, or one uint32 in pinned host memory owned by the caller for this workspace: with sync != 0 the call
+ *              then waits by polling this word, which the fused kernel stores to after the top-k is written (a fraction
+ *              of the cost of a stream synchronisation); ignored when the launch is not fused
+ *   sync       != 0: the results are complete and visible to the host when the call returns
  * n == 0 -> MAXSIM_EEMPTY (assert len(pids) > 0, colbert_ranker.py:76); n <= 16384 (BSIZE, colbert_ranker.py:11).
  */
+int64_t maxsim_rank_forward_workspace_bytes(int n);
 int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype, int Lq, const int64_t* pids, int n,
-                        int depth, float* scores_ws, int64_t* out_pids, float* out_scores, int sync, void* stream);
+                        int depth, void* workspace, int64_t* out_pids, float* out_scores, uint32_t* done_flag,
+                        int sync, void* stream);
 
 /*
  * Doc-sharded rerank, per-rank candidate filter (the reference reranks on one GPU only): this rank owns

@@ -57,10 +57,12 @@ def test_validation_without_launch(lib):
     assert L.maxsim_rerank_ex(ctypes.byref(iv), None, 0, None, None, None, 1, 0, 32, None, None) == lib.EEMPTY
     assert L.maxsim_rerank_ex(ctypes.byref(iv), None, 0, None, None, None, 0, 1, 32, None, None) == lib.OK
     assert L.maxsim_rerank_ex(ctypes.byref(iv), None, 0, None, None, None, 1, 1, 32, None, None) == lib.EINVAL
-    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 0, 10, None, None, None, 0, None) == lib.EEMPTY
-    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 20000, 10, None, None, None, 0, None) == lib.ERANGE
-    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 5, 0, None, None, None, 0, None) == lib.EINVAL
-    assert L.maxsim_rank_forward(None, None, 0, 32, None, 5, 1, None, None, None, 0, None) == lib.EINVAL
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 0, 10, None, None, None, None, 0, None) == lib.EEMPTY
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 20000, 10, None, None, None, None, 0, None) == lib.ERANGE
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 5, 0, None, None, None, None, 0, None) == lib.EINVAL
+    assert L.maxsim_rank_forward(None, None, 0, 32, None, 5, 1, None, None, None, None, 0, None) == lib.EINVAL
+    assert L.maxsim_rank_forward(ctypes.byref(iv), None, 0, 32, None, 5, 1, None, None, None, None, 0, None) == lib.EINVAL   # no workspace
+    assert L.maxsim_rank_forward_workspace_bytes(1000) == 4064
     assert L.maxsim_doc_table_bytes(1000) == 16000 and L.maxsim_doc_table_bytes(0) == 0
     assert L.maxsim_build_doc_table(None, None, None, 0, None, None) == lib.OK
     assert L.maxsim_build_doc_table(None, None, None, 4, None, None) == lib.EINVAL

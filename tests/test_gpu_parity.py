@@ -555,12 +555,11 @@ def test_fp32_bf16x3_mode_is_fp32_accurate(ca):
         rs = {m: ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=128, index_dtype=torch.float32, fp32_mode=m)
               for m in ("exact", "bf16x3")}
         offs = rs["exact"].doclens_pfxsum
-        nopad = torch.zeros(200, dtype=torch.long)
         err = {}
         for m, r in rs.items():
-            r.d_pad_len.zero_()                                    # no 0-floor: pure sum-of-max
+            pad = r.d_pad_len.cpu()                                # the reference's bucket strides (0-floor where it pads)
             sc = r.score_candidates(Q, cand).cpu().double().numpy()
-            ref = np.stack([ragged_scores_f64(emb, doclens, offs, nopad, Q[qi], cand[qi].tolist()) for qi in range(3)])
+            ref = np.stack([ragged_scores_f64(emb, doclens, offs, pad, Q[qi], cand[qi].tolist()) for qi in range(3)])
             err[m] = np.abs(sc - ref).max() / (scale * scale)
         assert err["exact"] <= 2e-5 and err["bf16x3"] <= 2e-5, err
         assert err["bf16x3"] <= 4 * err["exact"] + 1e-6, err

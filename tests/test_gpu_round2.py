@@ -308,3 +308,50 @@ def test_non_finite_inputs_contract(ca):
     # the dense operator seam behaves the same way
     out = ca.score(Q.cuda(), D.cuda(), torch.ones(1, 32).cuda(), torch.ones(6, 20).cuda()).cpu()[0]
     assert out[0] == float("inf") and torch.isfinite(out[2]) and abs(out[1] - exp[1]) <= ATOL32
+
+
+# ------------------------------------------------------------------------------------------------------
+# small launches: docs split over several waves, top-k fused into the rerank launch
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("lo,hi", [(180, 180), (1, 180), (129, 400), (300, 700)])
+def test_split_launch_is_bit_identical_to_the_batched_kernel(ca, dtype, lo, hi):
+    """A doc streamed by 2 or 4 waves (one query x few candidates) scores bit-for-bit what the one-wave-per-doc kernel
+    gives the same (query, doc) pair inside a big batch: max is exact and the sum over query tokens uses the same tree."""
+    gen = torch.Generator().manual_seed(lo * 7 + hi)
+    nd = 700
+    doclens = torch.randint(lo, hi + 1, (nd,), generator=gen).tolist()
+    doclens[5] = 0
+    parts = [nrm(gen, sum(doclens), 128).to(dtype)]
+    r = ca.ColbertRanker(parts=parts, parts_doclens=[doclens], dim=128, index_dtype=dtype)
+    Q = nrm(gen, 40, 32, 128).cuda()
+    cand = torch.stack([torch.randperm(nd, generator=gen)[:600] for _ in range(40)]).cuda()
+    cand[0, 11], cand[0, 12] = -1, 5
+    big = r.score_candidates(Q, cand)                                  # 24000 docs: the regular kernel
+    for n in (1, 2, 3, 37, 200, 600):                                  # one query x n docs: the split forms
+        small = r.score_candidates(Q[:1], cand[:1, :n])
+        assert torch.equal(small, big[:1, :n]), n
+    two = r.score_candidates(Q[:2], cand[:2, :100])
+    assert torch.equal(two, big[:2, :100])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float16])
+def test_fused_rank_forward_repeated_calls(ca, dtype):
+    """The one-launch rank_forward (top-k in the last workgroup): many calls in a row on one workspace (its counters must
+    come back to zero), list lengths around the sort's sizes, every call equal to rerank + top-k done separately."""
+    gen = torch.Generator().manual_seed(5)
+    nd = 3000
+    doclens = torch.randint(100, 181, (nd,), generator=gen).tolist()
+    parts = [nrm(gen, sum(doclens), 128).to(dtype)]
+    r = ca.ColbertRanker(parts=parts, parts_doclens=[doclens], dim=128, index_dtype=dtype)
+    for it, n in enumerate([1000, 1, 2, 255, 256, 257, 1000, 1023, 1024, 1025, 2047, 2048, 2049, 1000, 3000, 1000, 1000]):
+        q = nrm(gen, 32, 128)
+        Q = q.unsqueeze(0).permute(0, 2, 1)
+        pids = torch.randperm(nd, generator=gen)[:n].tolist()
+        depth = [100, 10, 1, 3000][it % 4]
+        gp, gs = r.rank_forward(Q, pids, depth=depth)
+        sc = r.score_candidates(q.unsqueeze(0), torch.tensor([pids]))
+        es, ei = torch.sort(sc[0].cpu(), descending=True, stable=True)
+        k = min(depth, n)
+        assert gs == es[:k].tolist(), (it, n)
+        assert gp == [pids[i] for i in ei[:k].tolist()], (it, n)
