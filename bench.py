@@ -132,6 +132,10 @@ def main():
                     help="candidates per query on each GPU (0 = 1000 / N; diagnostic: --nq 2048 --ncand 125 is one rank's share of N = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the host-side legs (cpu_baseline and the single-query latency probe): profiling runs")
+    ap.add_argument("--as-rank", type=int, default=-1,
+                    help="diagnostic, with --gpus 1: run ONE rank's share of an --of N job on this GPU (256*N queries, candidates "
+                         "drawn over all N shards, shard filter + rerank + local top-k; no exchange unless --force-dist)")
+    ap.add_argument("--of", type=int, default=8, help="see --as-rank")
     ap.add_argument("--force-dist", action="store_true",
                     help="with --gpus 1: still initialise RCCL (world 1) and run the all_gather + merge leg")
     args = ap.parse_args()
@@ -187,11 +191,13 @@ def main():
     ntok = sum(doclens)
     idx = build_index(ntok, H, dev, 1234 + rank, dtype)
     ranker = colbert_amd.ColbertRanker.from_device_tensor(idx, doclens, fp32_mode=args.fp32_mode)
-    lo, hi = rank * ndocs, (rank + 1) * ndocs
+    sim = args.as_rank >= 0 and world == 1
+    job_world, job_rank = (args.of, args.as_rank) if sim else (world, rank)
+    lo, hi = job_rank * ndocs, (job_rank + 1) * ndocs
     sharded = ShardedRanker(ranker, lo, hi)        # N > 1: re-buckets the shard by the strides of the whole index
     sharded.force_exchange = args.force_dist
 
-    nq = (args.nq or NQ) * world
+    nq = (args.nq or NQ) * job_world
     ncand_q = args.ncand or NCAND                   # candidates per query, over all shards
     total = args.warmup + args.steps
     gq = torch.Generator(device=dev).manual_seed(1)            # same queries on every rank
@@ -200,9 +206,9 @@ def main():
     Q = Q.to({"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[q_dtype])
     # candidate lists: GLOBAL pids, the same on every rank (same seed); a ring of NB distinct batches (one batch of docs
     # is >= 23 GB of tokens >> the 256 MB Infinity Cache, so re-using a batch NB steps later still reads HBM)
-    NB = total if world == 1 else min(total, 8)
+    NB = total if job_world == 1 else min(total, 8)
     gc = torch.Generator(device=dev).manual_seed(2)
-    cands = torch.randint(0, world * ndocs, (NB, nq, ncand_q), generator=gc, device=dev, dtype=torch.int64)
+    cands = torch.randint(0, job_world * ndocs, (NB, nq, ncand_q), generator=gc, device=dev, dtype=torch.int64)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(total)]
     timed = {"i": 0}
@@ -219,13 +225,15 @@ def main():
     def step(i, batches):
         timed["i"] = i
         cand_global = batches[i % batches.size(0)]
-        if world == 1 and not use_dist:
+        if world == 1 and not use_dist and not sim:
             scores = timed_score(Q, cand_global)
             return ranker.topk(scores, cand_global, min(TOPK, ncand_q))
         # the shipped sharded path: shard filter -> rerank -> local top-k (global pids) ...
         top_p, top_s = sharded.local_topk(Q, cand_global, TOPK)
         # ... then the ONE exchange step (all_gather over xGMI) + the per-query merge on the side stream: batch i's
         # exchange overlaps batch i+1's rerank kernel; every batch is complete before the timed region ends
+        if sim and not use_dist:
+            return top_p, top_s
         h = sharded.exchange_async(top_p, top_s, TOPK)
         if os.environ.get("MAXSIM_BENCH_NO_PIPELINE"):   # diagnostic: resolve the exchange before the next batch is issued
             h.result()
@@ -336,7 +344,8 @@ def main():
                                    f"{'~120 (8..180 ragged)' if wl['ragged'] else LD} tokens, dim {H}, "
                                    f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}"
                                    + (f", doc-sharded x{world}: candidates uniform over all {world * ndocs} pids, shard filter + "
-                                      f"local top-{TOPK} + RCCL all_gather + merge" if world > 1 else ""),
+                                      f"local top-{TOPK} + RCCL all_gather + merge" if world > 1 else "")
+                                   + (f", SIMULATED rank {job_rank} of {job_world} (one rank's share of the job, no exchange)" if sim else ""),
                        "queries_per_step": nq, "candidates_per_query": ncand_q, "docs_per_gpu": ndocs,
                        "index_dtype": args.index_dtype, "q_dtype": q_dtype, "fp32_mode": args.fp32_mode, "parallelism": f"doc-shard x{world}"},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -369,20 +378,29 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     """The reference's online call: ONE query x 1000 candidates through rank_forward (faiss_indexers.py:234), python
     list in, python lists out, host-synchronous -- latency, not throughput.  `gpu_span_ms` is the time between two HIP
     events recorded on the launch stream right before and after the call (both kernels + the gap between them);
-    `host_ms` = end-to-end minus that span.  The kernel's own duration is in profiles/r02_single_query_*."""
+    `host_ms` = end-to-end minus that span (the events themselves add a few us to the span: the kernel's own duration is
+    in profiles/r02_single_query_*)."""
     Q1 = Q[:1].float().permute(0, 2, 1).contiguous()           # [1, h, Lq] as ColbertRetriever.search hands it over
     out = {"call": "rank_forward(Q[1,h,Lq], 1000 pids, depth=100) -> python lists"}
     lat, span = [], []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    for it in range(140):
+    import ctypes
+    from colbert_amd import _lib
+    Qt = Q1.permute(0, 2, 1).contiguous()
+    for it in range(160):
         pids1 = cands[it % cands.size(0), it % cands.size(1)].tolist()        # fresh docs every call: HBM, not cache
         if it % 2 == 0:
             t1 = time.perf_counter()
             ranker.rank_forward(Q1, pids1, depth=TOPK)
             lat.append(time.perf_counter() - t1)
         else:
+            # the same library call without its wait, between two HIP events on the launch stream: GPU time of the call
+            ws = ranker._tls.ws
+            ws.pin_in[:len(pids1)] = pids1
+            st = torch.cuda.current_stream().cuda_stream
             e0.record()
-            ranker.rank_forward(Q1, pids1, depth=TOPK)
+            _lib.lib.maxsim_rank_forward(ctypes.byref(ranker._iv), Qt.data_ptr(), 0, LQ, ws.in_ptr, len(pids1), TOPK,
+                                         ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, None, 0, st)
             e1.record()
             e1.synchronize()
             span.append(e0.elapsed_time(e1))
@@ -391,7 +409,8 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     ntok = len(pids1) * int(ranker.d_doclens[0].item())
     out.update({"median_ms": round(med, 4), "min_ms": round(lat[0] * 1e3, 4), "gpu_span_ms": round(gspan, 4),
                 "host_ms": round(max(med - gspan, 0.0), 4), "queries_per_s_sequential": round(1e3 / med, 1),
-                "algorithmic_GBps_over_gpu_span": round((ntok * H * esize + LQ * H * 4) / (gspan * 1e-3) / 1e9, 1)})
+                "algorithmic_GBps_over_gpu_span": round((ntok * H * esize + LQ * H * 4) / (gspan * 1e-3) / 1e9, 1),
+                "kernel_profile": "profiles/r02_single_query_kernel_stats.csv"})
     # 16 queries per launch (a small server batch): rerank kernel only, HIP events
     c16 = cands[0, :16].contiguous()
     ks = []

@@ -194,12 +194,9 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   return check_launch();
 }
 
-// ep != NULL: the caller wants the fused top-k epilogue; *fused tells whether the launch carried it (only the small-launch
-// forms of the h = 128 kernel do) -- if not, the caller ranks the score rows with maxsim_topk.
 static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, const int32_t* q_len,
                        const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
-                       hipStream_t st, const Epilogue* ep = nullptr, bool* fused = nullptr) {
-  if (fused) *fused = false;
+                       hipStream_t st) {
   const int h = iv.h, index_dtype = iv.index_dtype;
   const int64_t n_tokens = iv.n_tokens, n_docs = iv.n_docs;
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
@@ -231,14 +228,9 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
   const bool aligned = (((uintptr_t)Q | (uintptr_t)iv.index) & 15) == 0;  // the streaming kernels move 16-byte pieces
   const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
   if (h == 128 && stream_ok) {
-    if (Lq <= 32) {  // small launches: docs split over several waves, top-k fused into the last workgroup
-      if (ep) p.ep = *ep;
-      const int rc = launch_stream_small(p, index_dtype, ep != nullptr, st);
-      p.ep = Epilogue{};
-      if (rc != MAXSIM_ERANGE) {
-        if (fused) *fused = ep != nullptr && rc == MAXSIM_OK;
-        return rc;
-      }
+    if (Lq <= 32) {  // small launches of a 16-bit index: docs split over several waves
+      const int rc = launch_stream_small(p, index_dtype, st);
+      if (rc != MAXSIM_ERANGE) return rc;
     }
     return for_query_slices(p, [&] { return launch_stream_rerank(p, index_dtype, st); });
   }
@@ -297,6 +289,16 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
   return check_launch();
 }
 
+// short lists: rank by counting, ncand / 16 workgroups per query (maxsim_topk.h)
+static int topk_count(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
+                      int64_t* out_pids, int32_t* counter, uint32_t* done_flag, uint32_t ticket, hipStream_t st) {
+  const int groups = (ncand + TOPK_CAND_PER_WG - 1) / TOPK_CAND_PER_WG;
+  if ((int64_t)nq * groups > 0x7fffffffLL) return MAXSIM_ERANGE;
+  hipLaunchKernelGGL(k_topk_count, dim3((unsigned)(nq * groups)), dim3(256), 0, st, scores, pids, ncand, k, out_scores,
+                     out_pids, groups, counter, done_flag, ticket);
+  return check_launch();
+}
+
 int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
                 int64_t* out_pids, void* stream) {
   if (nq < 0 || ncand < 0 || k < 1) return MAXSIM_EINVAL;
@@ -304,20 +306,7 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
   if (ncand > 16384) return MAXSIM_ERANGE;
   if (nq == 0) return MAXSIM_OK;
   if (!scores || !out_scores || !out_pids) return MAXSIM_EINVAL;
-  if (ncand <= 2048) {  // short lists: the register / lane-exchange workgroup sort (maxsim_topk.h)
-    const int R = ncand <= 256 ? 1 : (ncand <= 512 ? 2 : (ncand <= 1024 ? 4 : 8));
-    if (k <= 256 * R) {
-      const dim3 grid((unsigned)nq), block(256);
-      hipStream_t st = (hipStream_t)stream;
-      switch (R) {
-        case 1: hipLaunchKernelGGL(k_topk_small<1>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
-        case 2: hipLaunchKernelGGL(k_topk_small<2>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
-        case 4: hipLaunchKernelGGL(k_topk_small<4>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
-        default: hipLaunchKernelGGL(k_topk_small<8>, grid, block, 0, st, scores, pids, ncand, k, out_scores, out_pids); break;
-      }
-      return check_launch();
-    }
-  }
+  if (ncand <= 2048) return topk_count(scores, pids, nq, ncand, k, out_scores, out_pids, nullptr, nullptr, 0, (hipStream_t)stream);
   int P = 2;
   while (P < ncand) P <<= 1;
   const int ldsb = P * 8;
@@ -339,30 +328,26 @@ int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype,
   if (n > 16384) return MAXSIM_ERANGE;
   if (!workspace || ((uintptr_t)workspace & 15) != 0 || !out_pids || !out_scores) return MAXSIM_EINVAL;
   // workspace: 64 bytes of counters (zero between calls) | n floats (the score vector, colbert_ranker.py:122)
-  int32_t* const counters = (int32_t*)workspace;
+  int32_t* const counter = (int32_t*)workspace;
   float* const scores = (float*)((char*)workspace + 64);
+  hipStream_t st = (hipStream_t)stream;
   const int k = depth < n ? depth : n;
+  int rc = rerank_impl(*iv, Q, q_dtype, nullptr, nullptr, pids, 1, n, Lq, scores, st);
+  if (rc != MAXSIM_OK) return rc;
+  // colbert_ranker.py:128-130.  Short lists: the counting kernel, whose last workgroup stores a ticket to done_flag
+  const bool poll = sync && done_flag && n <= 2048 && MAXSIM_KNOB("MAXSIM_POLL", 1) != 0;
   static std::atomic<uint32_t> tickets{0};
   uint32_t ticket = ++tickets;
   if (ticket == 0) ticket = ++tickets;
-  Epilogue ep{};
-  ep.counters = counters;
-  ep.out_s = out_scores;
-  ep.out_p = out_pids;
-  ep.done_flag = (sync && done_flag) ? done_flag : nullptr;
-  ep.ticket = ticket;
-  ep.k = k;
-  bool fused = false;
-  int rc = rerank_impl(*iv, Q, q_dtype, nullptr, nullptr, pids, 1, n, Lq, scores, (hipStream_t)stream, &ep, &fused);
+  if (n <= 2048)
+    rc = topk_count(scores, pids, 1, n, k, out_scores, out_pids, counter, poll ? done_flag : nullptr, ticket, st);
+  else
+    rc = maxsim_topk(scores, pids, 1, n, k, out_scores, out_pids, stream);
   if (rc != MAXSIM_OK) return rc;
-  if (!fused) {
-    rc = maxsim_topk(scores, pids, 1, n, k, out_scores, out_pids, stream);  // colbert_ranker.py:128-130
-    if (rc != MAXSIM_OK) return rc;
-  }
   if (!sync) return MAXSIM_OK;
-  if (fused && ep.done_flag) {
-    // the kernel's last workgroup stores `ticket` to the (host-visible) word after the top-k is written: spinning on it
-    // costs a fraction of a stream synchronisation.  Bounded: fall back to the runtime if it does not show up.
+  if (poll) {
+    // polling the host-visible word costs a fraction of a stream synchronisation.  Bounded: if the ticket does not
+    // show up (the memory is not host-coherent after all), fall back to the runtime's wait.
     volatile uint32_t* f = done_flag;
     for (int spins = 0; spins < (1 << 22); ++spins) {
       if (*f == ticket) {
@@ -372,7 +357,7 @@ int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype,
       __builtin_ia32_pause();
     }
   }
-  return hipStreamSynchronize((hipStream_t)stream) == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
+  return hipStreamSynchronize(st) == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
 }
 
 int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,

@@ -21,16 +21,6 @@ constexpr float NEG_INF = -__builtin_huge_valf();
 
 enum : int { MODE_RERANK = 0, MODE_DENSE = 1 };
 
-// Fused rank_forward epilogue (maxsim_rank_forward; small-launch kernels only): the last workgroup of a query to finish
-// sorts the query's score row and writes its top-k.  counters: [nq + 1] int32, zero before the launch, left zero.
-struct Epilogue {
-  int32_t* counters;
-  float* out_s;
-  int64_t* out_p;
-  uint32_t* done_flag;  // NULL, or a host-visible word that receives `ticket` once every query's top-k is written
-  uint32_t ticket;
-  int k;
-};
 struct Params {
   // token matrix: the HBM-resident index (rerank) or D[nd,Ld,h] (dense)
   const void* index;
@@ -59,8 +49,7 @@ struct Params {
   // scheduling
   int dpw;     // docs per workgroup
   int nchunk;  // ceil(ncand / dpw)
-  int split;   // small-launch kernels: waves per doc (2 or 4); otherwise 1
-  Epilogue ep; // fused top-k (small-launch kernels with EPI), else zeros
+  int split;   // split-doc kernels: waves per doc (2 or 4); otherwise 1
 };
 
 // Kernel arguments: the read-only tables are passed as individual `const __restrict__` pointers (not inside
@@ -76,8 +65,7 @@ struct Scalars {
       const int32_t* __restrict__ a_doclens, const int32_t* __restrict__ a_pad_len,                         \
       const void* __restrict__ a_Q, const int32_t* __restrict__ a_q_len, const int64_t* __restrict__ a_cand, \
       float* __restrict__ a_scores, const void* __restrict__ a_q_mask, const void* __restrict__ a_d_mask,   \
-      int32_t* __restrict__ a_argmax, const void* __restrict__ a_doc_table, const maxsim::Scalars sc,      \
-      const maxsim::Epilogue ep
+      int32_t* __restrict__ a_argmax, const void* __restrict__ a_doc_table, const maxsim::Scalars sc
 #define KARGS_TO_PARAMS                                                                                     \
   maxsim::Params p;                                                                                         \
   p.index = a_index; p.n_tokens = sc.n_tokens; p.tok_offsets = a_tok_offsets; p.doclens = a_doclens;        \
@@ -85,12 +73,12 @@ struct Scalars {
   p.nq = sc.nq; p.ncand = sc.ncand; p.Lq = sc.Lq; p.h = sc.h; p.scores = a_scores; p.q_mask = a_q_mask;     \
   p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk;         \
   p.q_dtype = sc.q_dtype; p.argmax = a_argmax; p.q_tok0 = sc.q_tok0; p.accum = sc.accum; p.doc_table = a_doc_table;       \
-  p.split = sc.split; p.ep = ep
+  p.split = sc.split
 #define KARGS_PASS(p)                                                                                       \
   (p).index, (p).tok_offsets, (p).doclens, (p).pad_len, (p).Q, (p).q_len, (p).cand, (p).scores, (p).q_mask, \
       (p).d_mask, (p).argmax, (p).doc_table, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
                                     (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype, (p).q_tok0, (p).accum,       \
-                                    (p).split }, (p).ep
+                                    (p).split }
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {

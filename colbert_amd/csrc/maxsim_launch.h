@@ -83,9 +83,9 @@ inline int pick_docs_per_wave(const Params& p, int waves) {
 // tu_stream.hip: the h = 128 register-query kernel.  index_dtype: MAXSIM_F32 / F16 / BF16 / F32_FAST / F32_BF16X3.
 int launch_stream_rerank(Params& p, int index_dtype, hipStream_t st);
 int launch_stream_dense_f32(Params& p, hipStream_t st);
-// tu_stream_small.hip: small launches of the same kernel -- a doc split over several waves, optionally with the fused
-// top-k epilogue described by p.ep.  MAXSIM_ERANGE = not a launch these forms serve (take the regular path).
-int launch_stream_small(Params& p, int index_dtype, bool epi, hipStream_t st);
+// tu_stream_small.hip: small launches of the same kernel with each doc split over several waves (bit-identical scores).
+// MAXSIM_ERANGE = not a launch this form serves (take the regular path).
+int launch_stream_small(Params& p, int index_dtype, hipStream_t st);
 // tu_bigh_rerank.hip / tu_bigh_dense.hip: the LDS-query kernel (any 16 <= h <= 1024); dt: MAXSIM_F32 / F16 / BF16.
 // Return MAXSIM_ERANGE when the query image does not fit in LDS.
 int launch_bigh_rerank(Params& p, int dt, hipStream_t st);

@@ -22,7 +22,6 @@
 // There is no workgroup barrier: waves pace their own ring with counted s_waitcnt vmcnt.
 #pragma once
 #include "maxsim_common.h"
-#include "maxsim_sort.h"
 
 namespace maxsim {
 
@@ -529,14 +528,14 @@ constexpr int QT_2X16 = 48;  // 32 query tokens as two 16-column blocks of v_mfm
 // v_mfma_f32_16x16x4_f32 -- half the matrix-pipe time of the 32-column form, half the query registers.
 // Small launches (the reference's online call is ONE query x ~1000 candidates, faiss_indexers.py:234):
 //   SPLITK  a doc is streamed by p.split (2 or 4) waves of the workgroup, each a slice of its tokens -- with one wave per
-//           doc a 1000-candidate launch keeps half the SIMDs of the chip idle and every wave walks 6 tiles serially;
-//   EPI     the last workgroup of a query to finish also sorts the query's score row and writes the top-k (and a
-//           completion word the host can spin on): rank_forward is ONE launch instead of two.
+//           doc a 1000-candidate launch leaves half the wave slots of the chip empty and every wave walks 6 tiles serially.
+//           Measured (tools/bench_small.py, 1 query x 1000 docs x 180 tokens): fp16 index 31 -> 17 us; the fp32 index
+//           is already bandwidth-bound with one wave per doc (16 KiB tiles: 16 MB in flight) and does not gain.
 constexpr int SPLIT_MAX_DOCS = 8;  // docs per team of waves in a SPLITK launch (their parked maxima live in LDS)
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false, bool EPI = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
-  static_assert(!(SPLITK || EPI) || (MODE == MODE_RERANK && QT == QT_2X16 && WAVES == 4), "small-launch forms: two 16-column blocks only");
+  static_assert(!SPLITK || (MODE == MODE_RERANK && QT == QT_2X16 && WAVES == 4), "split form: two 16-column blocks only");
   static_assert(QT == 32 || (MODE == MODE_RERANK && ((QT == 16 && DT == MAXSIM_F32) ||
                                                      (QT == QT_2X16 && DT != F32S))),
                 "16-column forms: rerank only (the fp16-split fast mode keeps the 32x32x16 form: 1 % faster there)");
@@ -592,7 +591,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     }
     prev_issued = t.kind != 0;
   }
-  if (!SPLITK && !EPI && nissued == 0) {  // (the small-launch forms meet at workgroup barriers below: no early exit)
+  if (!SPLITK && nissued == 0) {  // (the split form meets at a workgroup barrier below: no early exit)
     // nothing to stream: every slot of this wave is a padding slot (-inf) or an empty doc (0) -- e.g. the tail of a
     // doc-sharded candidate row (maxsim_shard_candidates).  Retire before the 16 KiB query tile is fetched.
     float* const srow0 = p.scores + (int64_t)qi * p.ncand + c_begin;
@@ -1028,33 +1027,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   } else {
     red.drain(C, dl, lane);
     if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
-  }
-  if constexpr (EPI) {
-    // ---- fused top-k: the query's last workgroup to get here ranks the row (colbert_ranker.py:128-130) -------------
-    __shared__ int s_last;
-    __threadfence();  // this wave's scores are visible device-wide ...
-    __syncthreads();  // ... for all four waves
-    if (threadIdx.x == 0) s_last = atomicAdd(p.ep.counters + qi, 1) == p.nchunk - 1;
-    __syncthreads();
-    if (s_last) {
-      __threadfence();
-      const float* row = p.scores + (int64_t)qi * p.ncand;
-      const int64_t* prow = p.cand + (int64_t)qi * p.ncand;
-      float* const os = p.ep.out_s + (int64_t)qi * p.ep.k;
-      int64_t* const op = p.ep.out_p + (int64_t)qi * p.ep.k;
-      if (p.ncand <= 1024) wg_topk_row<4>(row, prow, p.ncand, p.ep.k, os, op, (uint64_t*)lds, (int)threadIdx.x);
-      else wg_topk_row<8>(row, prow, p.ncand, p.ep.k, os, op, (uint64_t*)lds, (int)threadIdx.x);
-      __threadfence_system();  // the top-k (possibly in pinned host memory) before the completion word
-      __syncthreads();
-      if (threadIdx.x == 0) {
-        p.ep.counters[qi] = 0;  // leave the workspace zeroed for the next call
-        if (atomicAdd(p.ep.counters + p.nq, 1) == p.nq - 1) {  // last query of the launch
-          p.ep.counters[p.nq] = 0;
-          __threadfence_system();
-          if (p.ep.done_flag) __hip_atomic_store(p.ep.done_flag, p.ep.ticket, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        }
-      }
-    }
   }
 }
 

@@ -1,18 +1,85 @@
-// maxsim_topk.h -- per-query top-k and small utility kernels.
+// maxsim_topk.h -- per-query top-k (colbert_ranker.py:128-130) and small utility kernels.
 #pragma once
 #include "maxsim_common.h"
-#include "maxsim_sort.h"
 
 namespace maxsim {
 
-template <int R>
-__global__ void __launch_bounds__(256) k_topk_small(const float* __restrict__ scores, const int64_t* __restrict__ pids,
+// key = orderable(score) << 32 | ~position  -> descending key order = score desc, position asc.  Keys are unique.
+__device__ __forceinline__ uint32_t orderable(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unorderable(uint32_t k) {
+  uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+  return __uint_as_float(u);
+}
+
+// =============================================================================================
+// Short lists (ncand <= 2048; the reference's online call ranks ~1000 candidates): RANK BY COUNTING.  The rank of a
+// candidate is the number of keys above its own; keys are unique, so ranks are a permutation and every candidate with
+// rank < k writes its own output slot: no sorting network, no rounds, no cross-workgroup communication.  A workgroup
+// ranks 16 candidates of one query, 16 lanes per candidate (each lane compares against every 16th key of the row, held
+// in LDS; the 16 partial counts are added with DPP): ncand / 16 independent workgroups per query.
+// Why not sort: a sort of 1024 keys is ~55 DEPENDENT exchange steps on one workgroup and took 15-19 us whatever the
+// network (LDS bitonic 19 us, register/lane-exchange bitonic 16 us, radix selection + counting 14 us: the steps'
+// latency, not their work, is the cost) -- half the GPU time of a whole rank_forward.  Counting is n^2 / 2 comparisons but
+// all of them independent: ~3 us for one query, and it scales over the chip for a batch (256 x 1000: 16k workgroups).
+// done_flag (optional, host-visible): the last workgroup of the launch stores `ticket` to it after every output of
+// the launch is written (counter: one zeroed int32, left zero), so that a host thread can poll instead of calling
+// hipStreamSynchronize.
+// =============================================================================================
+constexpr int TOPK_CAND_PER_WG = 16;
+__global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ scores, const int64_t* __restrict__ pids,
                                                     int ncand, int k, float* __restrict__ out_s,
-                                                    int64_t* __restrict__ out_p) {
-  __shared__ uint64_t lds[256 * R];
-  const int q = blockIdx.x;
-  wg_topk_row<R>(scores + (int64_t)q * ncand, pids ? pids + (int64_t)q * ncand : nullptr, ncand, k,
-                 out_s + (int64_t)q * k, out_p + (int64_t)q * k, lds, threadIdx.x);
+                                                    int64_t* __restrict__ out_p, int groups, int32_t* counter,
+                                                    uint32_t* done_flag, uint32_t ticket) {
+  __shared__ uint64_t keys[2048];
+  const int tid = threadIdx.x;
+  const int q = blockIdx.x / groups, g = blockIdx.x - q * groups;
+  const float* srow = scores + (int64_t)q * ncand;
+  const int n16 = (ncand + 15) & ~15;
+  for (int i = tid; i < n16; i += 256)
+    keys[i] = i < ncand ? (((uint64_t)orderable(srow[i]) << 32) | (uint32_t)(~(uint32_t)i)) : 0ull;  // 0 < every real key
+  __syncthreads();
+  const int c = g * TOPK_CAND_PER_WG + (tid >> 4), part = tid & 15;
+  const uint64_t mine = keys[min(c, n16 - 1)];
+  int above = 0;
+#pragma unroll 4
+  for (int j = part; j < n16; j += 16) above += keys[j] > mine ? 1 : 0;
+  // sum over the 16 lanes of the candidate (one DPP row): xor 1, xor 2, then the two mirrors
+  above += __builtin_amdgcn_update_dpp(0, above, 0xB1, 0xF, 0xF, false);
+  above += __builtin_amdgcn_update_dpp(0, above, 0x4E, 0xF, 0xF, false);
+  above += __builtin_amdgcn_update_dpp(0, above, 0x141, 0xF, 0xF, false);
+  above += __builtin_amdgcn_update_dpp(0, above, 0x140, 0xF, 0xF, false);
+  if (part == 0 && c < ncand && above < k) {
+    const int pos = (int)(~(uint32_t)mine);
+    const float s = unorderable((uint32_t)(mine >> 32));
+    const int64_t pid = pids ? pids[(int64_t)q * ncand + pos] : (int64_t)pos;
+    float* os = out_s + (int64_t)q * k + above;
+    int64_t* op = out_p + (int64_t)q * k + above;
+    if (done_flag) {  // the host may read these while the kernel is still running: system-scope write-through
+      __hip_atomic_store(os, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(op, pid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else {
+      *os = s;
+      *op = pid;
+    }
+  }
+  // slots k' in [ncand, k) (k > ncand): (-inf, -1), written by the query's first workgroup
+  if (g == 0)
+    for (int i = ncand + tid; i < k; i += 256) {
+      out_s[(int64_t)q * k + i] = NEG_INF;
+      out_p[(int64_t)q * k + i] = -1;
+    }
+  if (done_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's outputs are acknowledged ...
+    __syncthreads();                                   // ... and so are the workgroup's
+    if (tid == 0 &&
+        __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1) {
+      __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // left zero for the next launch
+      __hip_atomic_store(done_flag, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // =============================================================================================

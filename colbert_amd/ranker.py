@@ -14,9 +14,11 @@ import ctypes
 import threading
 from itertools import accumulate
 
+import numpy as np
 import torch
 
 from . import _lib, index_io
+from ._pinned import PinnedBuffer
 from .scoring import _DT, _ptr, _stream
 
 BSIZE = 1 << 14  # colbert_ranker.py:11
@@ -54,18 +56,25 @@ def strides_from_histogram(hist):
 
 
 class _Workspace:
-    """Per-thread buffers of ``rank_forward``: pinned host memory the GPU reads the pid list from and writes the top-k
-    (and its completion word) to -- no memcpy calls on the way in or out -- and the device scratch of
+    """Per-thread buffers of ``rank_forward``: coherent pinned host memory the GPU reads the pid list from and writes the
+    top-k (and its completion word) to -- no memcpy calls on the way in or out -- and the device scratch of
     ``maxsim_rank_forward`` (zeroed counters + the score vector)."""
 
     def __init__(self, device):
-        self.pin_in = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
-        self.pin_out_p = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
-        self.pin_out_s = torch.empty(BSIZE, dtype=torch.float32).pin_memory()
-        self.pin_flag = torch.zeros(16, dtype=torch.int32).pin_memory()
+        # in: ordinary pinned memory (the host writes it before the launch; the GPU reads it through its caches --
+        # host-coherent memory would turn the 1000 lanes' 8-byte reads into 1000 uncached PCIe transactions)
+        self.pin_in_t = torch.empty(BSIZE, dtype=torch.int64).pin_memory()
+        self.pin_in = self.pin_in_t.numpy()
+        self.in_ptr = self.pin_in_t.data_ptr()
+        # out + completion word: host-COHERENT pinned memory (the host polls it while the kernel is still running)
+        self.pin = PinnedBuffer(BSIZE * 8 + BSIZE * 4 + 64)
+        self.pin_out_p = self.pin.view(np.int64, 0, BSIZE)
+        self.pin_out_s = self.pin.view(np.float32, BSIZE * 8, BSIZE)
+        self.pin_flag = self.pin.view(np.uint32, BSIZE * 12, 16)
+        self.pin_flag[:] = 0
+        self.out_p_ptr, self.out_s_ptr, self.flag_ptr = self.pin.ptr, self.pin.ptr + BSIZE * 8, self.pin.ptr + BSIZE * 12
         self.scratch = torch.zeros(int(_lib.lib.maxsim_rank_forward_workspace_bytes(BSIZE)), dtype=torch.uint8, device=device)
-        self.in_ptr, self.out_p_ptr, self.out_s_ptr = self.pin_in.data_ptr(), self.pin_out_p.data_ptr(), self.pin_out_s.data_ptr()
-        self.flag_ptr, self.scratch_ptr = self.pin_flag.data_ptr(), self.scratch.data_ptr()
+        self.scratch_ptr = self.scratch.data_ptr()
         torch.cuda.synchronize(device)          # the zero fill has landed before the first launch on any stream
 
 
@@ -170,6 +179,7 @@ class ColbertRanker:
                                                      self.n_docs, _ptr(self.d_doc_table), _stream(dev))
             _lib.check(rc, "maxsim_build_doc_table")
         self._iv = self._index_view()
+        self._iv_ref = ctypes.byref(self._iv)
 
     def _index_view(self):
         idt = _DT[self.tensor.dtype]
@@ -276,32 +286,38 @@ class ColbertRanker:
             if output_D_embedding:                                            # :131-136
                 return self._output_D(top_p[0], k)
             return top_p[0].tolist(), top_s[0].tolist()
-        # the online call: ONE library call (rerank + top-k enqueued back to back, then a stream sync).  The pid list goes
-        # in and the top-k comes out through pinned host buffers the kernels access directly: no memcpy calls, no
-        # allocations (per-thread workspace), no device tensors created
+        # the online call: ONE library call (rerank + top-k enqueued back to back, then a poll on the completion word the
+        # top-k kernel stores).  The pid list goes in through pinned host memory the kernels read directly and the top-k
+        # comes out through host-coherent pinned memory they write directly: no memcpy calls, no allocations (per-thread
+        # workspace), no device tensors created
         ws = getattr(self._tls, "ws", None)
         if ws is None:
             ws = self._tls.ws = _Workspace(dev)
         if type(pids) is list:
-            try:        # 1000 python ints: 14 us through array('q') against 50-75 us for torch.tensor(list)
+            try:        # 1000 python ints: 8 us through array('q') against 50-75 us for torch.tensor(list)
                 a = array.array("q", pids)
                 ctypes.memmove(ws.in_ptr, a.buffer_info()[0], 8 * n_pids)
             except (TypeError, OverflowError):
-                ws.pin_in[:n_pids] = torch.tensor(pids)
+                ws.pin_in[:n_pids] = np.asarray(pids, dtype=np.int64)
             pid_ptr = ws.in_ptr
         elif pids.is_cuda:
             pid_keep = pids.to(dev, torch.int64).contiguous()
             pid_ptr = pid_keep.data_ptr()
         else:
-            ws.pin_in[:n_pids] = pids
+            ws.pin_in[:n_pids] = pids.to(torch.int64).numpy()
             pid_ptr = ws.in_ptr
-        if torch.cuda.current_device() != dev.index and dev.index is not None:
-            with torch.cuda.device(dev):
-                rc = _lib.lib.maxsim_rank_forward(ctypes.byref(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids,
-                                                  k, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr, 1, _stream(dev))
-        else:
-            rc = _lib.lib.maxsim_rank_forward(ctypes.byref(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids,
-                                              k, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr, 1, _stream(dev))
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        switch = torch.cuda.current_device() != idx
+        if switch:
+            prev = torch.cuda.current_device()
+            torch.cuda.set_device(idx)
+        try:
+            rc = _lib.lib.maxsim_rank_forward(self._iv_ref, Qt.data_ptr(), _DT[qdt], Qt.size(1), pid_ptr, n_pids, k,
+                                              ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr, 1,
+                                              torch._C._cuda_getCurrentRawStream(idx))
+        finally:
+            if switch:
+                torch.cuda.set_device(prev)
         _lib.check(rc, "maxsim_rank_forward")
         return ws.pin_out_p[:k].tolist(), ws.pin_out_s[:k].tolist()
 

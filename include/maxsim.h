@@ -206,9 +206,9 @@ int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, co
 /*
  * One ColbertRanker.rank_forward (colbert_ranker.py:75-137) in one call: rerank of ONE query against n candidate
  * pids followed by the descending top-`depth` -- the reference's online call (faiss_indexers.py:234), where per-call
- * host overhead and launch latency, not bandwidth, dominate.  For h == 128, Lq <= 32, n <= 2048 and an F32 / F16 / BF16
- * index this is ONE kernel launch: docs are split over several waves when the launch is small, and the last workgroup
- * to finish sorts the score vector and writes the top-k.  Other shapes take two launches (rerank, then top-k).
+ * host overhead and launch latency, not bandwidth, dominate.  Two kernels are enqueued back to back on `stream` (the
+ * rerank -- with the docs of a 16-bit index split over several waves when the launch is small -- and the top-k, which
+ * for n <= 2048 ranks by counting on n / 16 workgroups); nothing is allocated, copied or synchronised in between.
  *   Q          [Lq, h] token-major, element type q_dtype (the shim undoes the reference's [1,h,Lq] permute)
  *   pids       [n] int64, any memory the GPU can read: device memory, or PINNED host memory (hipHostMalloc /
  *              torch pin_memory), which saves the H2D copy call
@@ -218,9 +218,10 @@ int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, co
  *              one call at a time.
  *   out_pids   [k] int64 and out_scores [k] float32, k = min(depth, n): device memory or pinned host memory (the kernel
  *              then writes the result straight to the host; no D2H copy call)
- *   done_flag  NULL, or one uint32 in pinned host memory owned by the caller for this workspace: with sync != 0 the call
- *              then waits by polling this word, which the fused kernel stores to after the top-k is written (a fraction
- *              of the cost of a stream synchronisation); ignored when the launch is not fused
+ *   done_flag  NULL, or one uint32 in host-COHERENT pinned memory (hipHostMallocCoherent) owned by the caller for this
+ *              workspace: with sync != 0 and n <= 2048 the call then waits by polling this word, which the top-k kernel's
+ *              last workgroup stores to after every output is written (a fraction of the cost of a stream
+ *              synchronisation); out_pids / out_scores must then be host-coherent too
  *   sync       != 0: the results are complete and visible to the host when the call returns
  * n == 0 -> MAXSIM_EEMPTY (assert len(pids) > 0, colbert_ranker.py:76); n <= 16384 (BSIZE, colbert_ranker.py:11).
  */

@@ -32,7 +32,7 @@ Qt = Q.permute(0, 2, 1).contiguous()
 st = torch.cuda.current_stream().cuda_stream
 def call(sync):
     ctypes.memmove(ws.in_ptr, array.array("q", nxt()).buffer_info()[0], 8000)
-    return _lib.lib.maxsim_rank_forward(ctypes.byref(r._iv), Qt.data_ptr(), 0, 32, ws.in_ptr, 1000, 100, ws.scores_ptr, ws.out_p_ptr, ws.out_s_ptr, sync, st)
+    return _lib.lib.maxsim_rank_forward(ctypes.byref(r._iv), Qt.data_ptr(), 0, 32, ws.in_ptr, 1000, 100, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr, sync, st)
 print("  maxsim_rank_forward(sync=1) incl. memmove  %.1f us" % T(lambda: call(1)))
 print("  maxsim_rank_forward(sync=0) launch cost    %.1f us" % T(lambda: call(0)))
 print("  2x tolist of 100                          %.1f us" % T(lambda: (ws.pin_out_p[:100].tolist(), ws.pin_out_s[:100].tolist())))
