@@ -545,8 +545,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   constexpr int ROWB = T::ROWB, TILE = T::TILE, NDMA = T::NDMA, RPD = T::RPD, LPR = T::LPR, NRD = T::NRD, NP = T::NP;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int qi = blockIdx.x / p.nchunk;
-  const int chunk = blockIdx.x - qi * p.nchunk;
+  int qi, chunk;
+  wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
   // unsplit: every wave has its own docs.  SPLITK: `split` consecutive waves form a team that shares dpwv docs; wave
   // `part` of the team streams the part-th slice of each doc (slices are whole 32-row tiles, cut as evenly as possible)
   const int split = SPLITK ? p.split : 1;
@@ -1113,8 +1113,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
   constexpr int ROWB = 512, HT = 16 * ROWB, NDMA = 8;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int qi = blockIdx.x / p.nchunk;
-  const int chunk = blockIdx.x - qi * p.nchunk;
+  int qi, chunk;
+  wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
   const int dpwv = p.dpw / WAVES;
   const int c_begin = chunk * p.dpw + wave * dpwv;
   const int ndoc = max(0, min(dpwv, p.ncand - c_begin));

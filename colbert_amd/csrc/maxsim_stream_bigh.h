@@ -148,8 +148,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   const uint32_t rowbytes = (uint32_t)p.h * ESZ;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  const int qblk = blockIdx.x / p.nchunk;
-  const int chunk = blockIdx.x - qblk * p.nchunk;
+  int qblk, chunk;
+  if constexpr (MODE == MODE_RERANK) {
+    wg_to_work((int)blockIdx.x, (p.nq + QB - 1) / QB, p.nchunk, qblk, chunk);
+  } else {  // all-pairs: query-block-major (a doc chunk's query blocks close in time re-read it from cache)
+    qblk = blockIdx.x / p.nchunk;
+    chunk = blockIdx.x - qblk * p.nchunk;
+  }
   const int q0 = qblk * QB;  // first query of this workgroup; queries past nq - 1 are clamped and not written
   const int dpwv = p.dpw / WAVES;
   const int c_begin = chunk * p.dpw + wave * dpwv;
