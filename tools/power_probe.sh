@@ -1,4 +1,6 @@
 #!/bin/bash
+# knobs live in the diagnostic build only: MAXSIM_OUT=tools/ab/diag.so colbert_amd/csrc/build.sh -DMAXSIM_DIAG
+export MAXSIM_LIB=${MAXSIM_LIB:-$PWD/tools/ab/diag.so}
 # On the GPU box: board power / shader clock while bench.py loops a workload.  usage: tools/power_probe.sh "<bench args>" ...
 for args in "$@"; do
   echo "== $args"

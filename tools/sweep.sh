@@ -1,4 +1,6 @@
 #!/bin/bash
+# knobs live in the diagnostic build only: MAXSIM_OUT=tools/ab/diag.so colbert_amd/csrc/build.sh -DMAXSIM_DIAG
+export MAXSIM_LIB=${MAXSIM_LIB:-$PWD/tools/ab/diag.so}
 # On the GPU box: A/B sweeps through bench.py (kernel ms and algorithmic GB/s per configuration).
 # usage: tools/sweep.sh            -> every workload, default kernels
 #        MAXSIM_VARIANT=1|2 ...    -> ablation builds of the h=128 stream kernel (DESIGN.md "Tuning knobs")
