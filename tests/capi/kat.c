@@ -1,6 +1,7 @@
 /* kat.c -- libmaxsim.so driven from plain C through include/maxsim.h (no Python, no torch): the reference's
  * known-answer test (colbert/modeling/BaseModel.py:70-75 -> [[21, 41]]), a masked variant, the zero-floor pair (SURVEY 8c golden 2),
- * a three-doc ragged rerank + top-k, and the error codes.  Built by __graft_entry__.build() with hipcc (the HIP
+ * a three-doc ragged rerank + top-k, the view-based entry points (doc table, q_mask, one-call rank_forward with pinned
+ * host buffers, doc-shard filter), and the error codes.  Built by __graft_entry__.build() with hipcc (the HIP
  * runtime is used only for hipMalloc/hipMemcpy); run by tests/test_gpu_parity.py::test_c_abi_from_plain_c.
  * Prints one line per check; exit status 0 iff all pass. */
 #include <hip/hip_runtime_api.h>
@@ -111,6 +112,63 @@ int main(void) {
     CHECK(rc == MAXSIM_OK && tp[0] == 2 && tp[1] == 0 && tp[2] == 1 && ts[0] == 1.5f && ts[2] == 0.0f, "topk: ties by list position");
     CHECK(maxsim_rerank(dI, MAXSIM_F32, NTOK, (const int64_t*)doff, (const int32_t*)dlen, NULL, 3, dQ, MAXSIM_F32, NULL,
                         (const int64_t*)dc, 1, 0, LQ, H, dsc, NULL) == MAXSIM_EEMPTY, "ncand == 0 -> EEMPTY (colbert_ranker.py:76)");
+
+    /* the view-based entry points on the same index: packed doc table, query-token mask (keep_nonzero,
+       training_utils.py:48-53), one-call rank_forward with pinned host buffers, the doc-shard candidate filter */
+    void* dtab = NULL;
+    hipMalloc(&dtab, (size_t)maxsim_doc_table_bytes(3));
+    CHECK(maxsim_build_doc_table((const int64_t*)doff, (const int32_t*)dlen, NULL, 3, dtab, NULL) == MAXSIM_OK, "build_doc_table");
+    maxsim_index_view iv;
+    memset(&iv, 0, sizeof iv);
+    iv.index = dI; iv.index_dtype = MAXSIM_F32; iv.h = H; iv.n_tokens = NTOK;
+    iv.tok_offsets = (const int64_t*)doff; iv.doclens = (const int32_t*)dlen; iv.pad_len = NULL; iv.n_docs = 3;
+    iv.doc_table = dtab;
+    const uint8_t keep[LQ] = {1, 0};  /* drop query token 1: doc 0 -> 1, doc 2 -> 1, doc 1 -> 0 */
+    void* dkeep = to_dev(keep, sizeof keep);
+    rc = maxsim_rerank_ex(&iv, dQ, MAXSIM_F32, NULL, (const uint8_t*)dkeep, (const int64_t*)dc, 1, 4, LQ, dsc, NULL);
+    hipDeviceSynchronize();
+    hipMemcpy(sc, dsc, sizeof sc, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && sc[0] == 0.0f && sc[1] == 1.0f && isinf(sc[2]) && sc[3] == 1.0f, "rerank_ex: doc table + q_mask");
+    rc = maxsim_rerank_ex(&iv, dQ, MAXSIM_F32, NULL, NULL, (const int64_t*)dc, 1, 4, LQ, dsc, NULL);
+    hipDeviceSynchronize();
+    hipMemcpy(sc, dsc, sizeof sc, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && sc[0] == 0.0f && sc[1] == 1.5f && sc[3] == 1.5f, "rerank_ex without mask = rerank");
+
+    int64_t* hp = NULL;  /* pinned host: pids in; coherent pinned: top-k and completion word out */
+    char* hout = NULL;
+    hipHostMalloc((void**)&hp, 4 * sizeof(int64_t), hipHostMallocDefault);
+    hipHostMalloc((void**)&hout, 256, hipHostMallocCoherent);
+    const int64_t list[3] = {1, 2, 0};
+    memcpy(hp, list, sizeof list);
+    memset(hout, 0, 256);
+    void* ws = NULL;
+    hipMalloc(&ws, (size_t)maxsim_rank_forward_workspace_bytes(3));
+    hipMemset(ws, 0, (size_t)maxsim_rank_forward_workspace_bytes(3));
+    hipDeviceSynchronize();
+    int64_t* op = (int64_t*)hout;
+    float* os = (float*)(hout + 64);
+    uint32_t* flag = (uint32_t*)(hout + 128);
+    for (int rep = 0; rep < 3; ++rep) {  /* repeated calls on one workspace: its counter returns to zero */
+      op[0] = op[1] = -7;
+      rc = maxsim_rank_forward(&iv, dQ, MAXSIM_F32, LQ, hp, 3, 2, ws, op, os, flag, 1, NULL);
+      CHECK(rc == MAXSIM_OK && op[0] == 2 && op[1] == 0 && os[0] == 1.5f && os[1] == 1.5f, "rank_forward: one call, pinned in/out, top-2");
+    }
+    CHECK(maxsim_rank_forward(&iv, dQ, MAXSIM_F32, LQ, hp, 0, 2, ws, op, os, flag, 1, NULL) == MAXSIM_EEMPTY, "rank_forward: no pids -> EEMPTY");
+
+    const int64_t glob[6] = {7, 12, 10, 3, 11, 10};  /* this shard owns global pids [10, 13) */
+    void* dg = to_dev(glob, sizeof glob);
+    int64_t *dl = NULL, *dgo = NULL;
+    int32_t* dcnt = NULL;
+    hipMalloc((void**)&dl, sizeof glob); hipMalloc((void**)&dgo, sizeof glob); hipMalloc((void**)&dcnt, 4);
+    rc = maxsim_shard_candidates((const int64_t*)dg, 1, 6, 10, 13, dl, dgo, dcnt, NULL);
+    int64_t loc[6], gl[6];
+    int32_t cnt = -1;
+    hipDeviceSynchronize();
+    hipMemcpy(loc, dl, sizeof loc, hipMemcpyDeviceToHost);
+    hipMemcpy(gl, dgo, sizeof gl, hipMemcpyDeviceToHost);
+    hipMemcpy(&cnt, dcnt, 4, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && cnt == 4 && loc[0] == 2 && loc[1] == 0 && loc[2] == 1 && loc[3] == 0 && loc[4] == -1 && loc[5] == -1 &&
+              gl[0] == 12 && gl[1] == 10 && gl[2] == 11 && gl[3] == 10 && gl[4] == -1, "shard_candidates: stable in-range compaction");
   }
   printf("%s\n", failures ? "FAILED" : "ALL OK");
   return failures ? 1 : 0;
