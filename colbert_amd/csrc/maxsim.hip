@@ -102,6 +102,10 @@ static int score_dense_impl(const void* Q, const void* D, const void* q_mask, co
   const bool stream_ok = aligned && (Lq <= 32 || (!argmax && Lq <= MAX_LQ_SLICED)) && p.n_tokens <= 0xffffffffLL;
   if (!argmax && stream_ok && dtype == MAXSIM_F32 && h == 128)
     return for_query_slices(p, [&] { return launch_stream_dense_f32(p, st); });
+  if (dtype != MAXSIM_F32 && aligned && Lq <= 32) {  // big all-pairs problems (the training step): GEMM blocking
+    const int rc = launch_allpairs(p, dtype, argmax != nullptr, st);
+    if (rc != MAXSIM_ERANGE) return rc;
+  }
   const int esz = dtype == MAXSIM_F32 ? 4 : 2;
   if (stream_ok && h >= 16 && h <= 1024 && ((h * esz) & 15) == 0) {
     int rc = argmax ? launch_bigh_dense(p, dtype, true, st)

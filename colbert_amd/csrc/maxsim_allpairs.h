@@ -1,0 +1,376 @@
+// maxsim_allpairs.h -- the all-pairs (training-form) MaxSim as a register-blocked, K-sliced GEMM with a fused
+// max / arg-max / sum epilogue: 16-bit Q and D of any width h that is a multiple of 32 (the reference trains at dim 768,
+// proj_conf/dense.yaml:8), Lq <= 32 query tokens, Ld <= 384 doc tokens (doc_maxlen, dense.yaml:7).
+//
+// Reference: BaseModel.score (colbert/modeling/BaseModel.py:39-46) as ColbertModel.forward calls it on the gathered batch
+// (colbert/modeling/colbert_model.py:87-90): simmat[q,d,m,n] = <Q[q,m] q_mask[q,m], D[d,n] d_mask[d,n]>, max over n
+// (torch.max: the FIRST maximal index is what autograd routes the gradient through), sum over m.  At the reference's
+// step (Q 272 x 32 x 768, D 544 x 384 x 768) that is a 208 896 x 8 704 x 768 GEMM = 2.79 PFLOP whose result never has
+// to exist: only 148 k scores and 4.7 M arg-max indices leave the kernel.
+//
+// The streaming kernel (maxsim_stream_bigh.h) computes this with one wave per 32-row doc tile and whole query images
+// in LDS: every 8 KB A fragment set is read for QB x 8 MFMAs, 2 KB of LDS traffic per MFMA at QB = 2 -- the LDS peak
+// (128 B/clk/CU) at full matrix rate, measured 22 % of the bf16 peak.  Here the blocking is a GEMM's:
+//   workgroup  8 waves = 4 (doc rows) x 2 (queries); tile = ONE doc (up to 128 R rows, R = 1..3) x 2 QB queries
+//   wave       R row blocks x QB queries of 32x32x16 MFMAs: R + QB fragment reads (1 KB each) per R QB MFMAs, 16 R QB
+//              accumulator registers.  (R, QB) = (1, 4), (2, 4), (3, 3): with 8 waves a wave has 256 registers, and
+//              3 x 4 blocks (192 accumulators) spilled; 3 x 3 = 0.67 KB of LDS reads per MFMA
+//   K          sliced by 32 dims: a slice is (128 R + 256) rows x 64 B, fetched by LDS-DMA (global_load_lds_dwordx4,
+//              no register staging) into a 3-stage ring: ONE workgroup barrier per slice, two slices in flight
+//   tiles      workgroups are persistent (one per CU: 120 KB of LDS) and walk (doc, query block) tiles; the ring runs
+//              across tile boundaries, so the next tile's first slices arrive during the epilogue.  XCD x takes the docs
+//              x, x + 8, ... and walks their query blocks in order: the ~32 workgroups of an XCD work on one or two docs at
+//              a time (the doc comes from that XCD's L2; the 13 MB of queries from the Infinity Cache)
+//   epilogue   per lane and query: running (max, first index) over its rows in increasing row order, lane halves combined
+//              with v_permlane32_swap, the four row-waves through LDS; masks multiply the finished similarities (exact
+//              for 0/1 masks, the only ones training uses: tokenizers.py:36,57); 0-padding rows past Ld never win.
+#pragma once
+#include "maxsim_common.h"
+
+namespace maxsim {
+
+struct AllPairsArgs {
+  const void* Q;       // [nq, Lq, h]
+  const void* D;       // [nd, Ld, h]
+  const void* q_mask;  // [nq, Lq] or NULL
+  const void* d_mask;  // [nd, Ld] or NULL
+  float* scores;       // [nq, nd]
+  int32_t* argmax;     // [nq, nd, Lq] (AM)
+  int mask_dtype, nq, nd, Lq, Ld, h;
+};
+
+template <int CTRL>
+__device__ __forceinline__ float ap_dpp(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xF, 0xF, false));
+}
+
+// The bare hardware barrier.  __syncthreads() is a workgroup fence + barrier, and the fence waits for EVERY outstanding
+// memory operation of the wave (s_waitcnt vmcnt(0)) -- including the LDS-DMA slices this kernel keeps in flight on
+// purpose: with it the ring never ran ahead and every slice exposed the full memory latency (35 % MFMA busy).  The loop
+// orders its data by hand: counted vmcnt for the slice that must have landed, then the barrier.
+__device__ __forceinline__ void wg_barrier() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+__device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are done, then the barrier (no vmcnt wait)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <int DT, int R, int QB, bool AM>
+__global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
+  static_assert(DT == MAXSIM_F16 || DT == MAXSIM_BF16, "16-bit operands");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int NQ = 2 * QB;                     // queries of a tile
+  constexpr int TM = 128 * R, TN = 32 * NQ;      // tile rows (doc tokens) / columns (query tokens)
+  constexpr int ROWS = TM + TN;                  // rows of a K slice image
+  constexpr int STAGE = ROWS * 64;               // bytes: 32 dims x 2 B per row
+  constexpr int NST = 4;                         // ring stages: slice g being read, g + 1 ready (its first fragments are
+                                                 // prefetched across the barrier), g + 2 and g + 3 in flight
+  constexpr int NI = ROWS / 16;                  // LDS-DMA instructions per slice (16 rows each): wave w issues w, w + 8, ...
+  constexpr int NMAX = (NI + 7) / 8;
+  constexpr int NAI = TM / 16;                   // instructions < NAI move doc rows, the others query rows
+  float* const ex_v = (float*)(lds + NST * STAGE);      // [NQ][4 wm][32]: per-wave (max) ...
+  int* const ex_i = (int*)(ex_v + NQ * 4 * 32);         // ... and (first index)
+  float* const dm_lds = (float*)(ex_i + NQ * 4 * 32);   // [TM]: d_mask row of the tile's doc
+  float* const qm_lds = dm_lds + TM;                    // [NQ * 32]: q_mask rows of the tile's queries
+  // (LDS-space views for the DMA destinations, cast here in uniform control flow: the generic -> LDS cast inside a
+  //  divergent branch trips a code-generation bug of this compiler)
+  typedef __attribute__((address_space(3))) char* lds_ptr_t;
+  const lds_ptr_t dm_dst = (lds_ptr_t)LPTR(dm_lds), qm_dst = (lds_ptr_t)LPTR(qm_lds);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = uni(tid >> 6), wm = wave & 3, wn = wave >> 2;
+  const int r = lane & 31, hh = lane >> 5;
+  const int nslices = a.h >> 5;
+  const int64_t rowb = (int64_t)a.h * 2;
+  const int nqb = (a.nq + NQ - 1) / NQ;
+  const int my_ndma = (NI - wave + 7) / 8;  // this wave's LDS-DMA instructions per slice (NMAX or NMAX - 1)
+
+  // ---- this workgroup's tiles: XCD x = id % 8 owns docs x, x + 8, ...; its workgroups walk (doc, query block) in order
+  const int x = blockIdx.x & 7, l = blockIdx.x >> 3, nl = max(1, (int)gridDim.x >> 3);
+  const int ndx = (a.nd - x + 7) >> 3;
+  const int ntx = ndx * nqb;  // tiles of this XCD
+  auto tile_doc = [&](int u) { return x + 8 * (u / nqb); };
+  auto tile_q0 = [&](int u) { return NQ * (u % nqb); };
+  const int my_tiles = l < ntx ? (ntx - l + nl - 1) / nl : 0;
+  const int total = my_tiles * nslices;  // slices this workgroup streams
+
+  // ---- fetch side.  DMA instruction j of this wave moves rows 16 (wave + 8 j) .. + 15 of the slice image: lane i -> row
+  //      + i / 4, 16-byte position i % 4, which receives source chunk (i % 4) ^ ((row >> 2) & 3) (fragment reads are
+  //      conflict-free).  Everything lane-dependent is a 32-bit offset computed ONCE (the address of an instruction is a
+  //      wave-uniform 64-bit base + that offset: no vector arithmetic per slice -- with two waves per SIMD in the same
+  //      phase, every VALU cycle spent here is a cycle the matrix pipe idles).
+  uint32_t off[NMAX];   // doc rows: min(row, Ld - 1) * rowb + chunk; query rows: (slot * Lq + min(token, Lq - 1)) * rowb + chunk
+  uint32_t off0[NMAX];  // query rows: the same for slot 0 (used for slots past nq in the last, partial query block)
+#pragma unroll
+  for (int j = 0; j < NMAX; ++j) {
+    const int ins = wave + 8 * j;
+    const int lr = 16 * ins + (lane >> 2);
+    const uint32_t chunk = (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) * 16);
+    if (ins < NAI) {
+      off[j] = (uint32_t)(min(lr, a.Ld - 1) * (int)rowb) + chunk;  // rows past Ld re-read the last row (never candidates)
+      off0[j] = 0;
+    } else {
+      const int slot = (lr - TM) >> 5, t = min((lr - TM) & 31, a.Lq - 1);  // tokens past Lq re-read the last token (weight 0)
+      off[j] = (uint32_t)((slot * a.Lq + t) * (int)rowb) + chunk;
+      off0[j] = (uint32_t)(t * (int)rowb) + chunk;
+    }
+  }
+  // the slice stream: (tile, slice) of the next slice to ISSUE, kept incrementally
+  int is_ti = 0, is_s = 0;
+  const char* is_dbase = nullptr;  // D + doc * Ld * rowb
+  const char* is_qbase = nullptr;  // Q + q0 * Lq * rowb
+  int is_nvalid = 0;               // query slots of the block that exist
+  auto issue_tile_setup = [&]() __attribute__((always_inline)) {
+    const int u = l + is_ti * nl;
+    const int d = tile_doc(u), q0 = tile_q0(u);
+    is_dbase = (const char*)a.D + ((int64_t)d * a.Ld) * rowb;
+    is_qbase = (const char*)a.Q + ((int64_t)q0 * a.Lq) * rowb;
+    is_nvalid = min(NQ, a.nq - q0);
+  };
+  auto issue = [&](int g) __attribute__((always_inline)) {  // issues slice g of this workgroup's stream (called with g = 0, 1, 2, ...)
+    if (is_s == 0) issue_tile_setup();
+    char* const dst = lds + (g % NST) * STAGE + wave * 1024;
+    const char* const dbase = is_dbase + is_s * 64;
+    const char* const qbase = is_qbase + is_s * 64;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) {
+      const int ins = wave + 8 * j;                                           // wave-uniform
+      if (ins >= NI) break;
+      const char* g_ptr;
+      if (ins < NAI) {
+        g_ptr = dbase + off[j];
+      } else {
+        const int lr = 16 * ins + (lane >> 2);
+        g_ptr = qbase + (((lr - TM) >> 5) < is_nvalid ? off[j] : off0[j]);   // slots past nq re-read slot 0
+      }
+#if !defined(AP_ABLATE) || AP_ABLATE != 2  // (diagnostic builds: -DAP_ABLATE=1 no MFMA, 2 no DMA, 3 no fragment reads)
+      __builtin_amdgcn_global_load_lds(GPTR(g_ptr), LPTR(dst + j * 8192), 16, 0, 0);
+#else
+      asm volatile("" ::"v"(g_ptr));
+#endif
+    }
+    if (++is_s == nslices) { is_s = 0; ++is_ti; }
+  };
+
+  // ---- compute side: fragment addresses inside a stage
+  //      A fragment of row block b, k-step ks: row 32 b + r, chunk 2 ks + hh at position chunk ^ ((row >> 2) & 3)
+  const int swz = (r >> 2) & 3;
+  f32x16 acc[R][QB];
+#pragma unroll
+  for (int b = 0; b < R; ++b)
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[b][q] = (f32x16)(0.0f);
+
+  // fragment sets, double-buffered: while the MFMAs of one k-step run, the next k-step's fragments are on their way from
+  // LDS (a workgroup's waves hit the barrier together; without this overlap the LDS read phase -- 96 KB per slice and CU,
+  // 768 cycles at 128 B/clk -- and the MFMA phase -- 1152 cycles per SIMD -- serialise: measured 35 % MFMA busy)
+  u32x4 fa[2][R], fb[2][QB];
+#if defined(AP_ABLATE) && AP_ABLATE == 3
+  for (int i = 0; i < 2; ++i) {
+    for (int b = 0; b < R; ++b) fa[i][b] = (u32x4)(0x3f803f80u);
+    for (int q = 0; q < QB; ++q) fb[i][q] = (u32x4)(0x3f803f80u);
+  }
+#endif
+  auto load_frags = [&](int set, int g, int ks) __attribute__((always_inline)) {
+    const char* const st = lds + (g % NST) * STAGE;
+    const int pos = ((2 * ks + hh) ^ swz) * 16;
+#if defined(AP_ABLATE) && AP_ABLATE == 3
+    asm volatile("" ::"v"(st), "v"(pos));
+    return;
+#endif
+    // ds_read_b128 by hand: the compiler would wait for a set with s_waitcnt lgkmcnt(0) -- i.e. also for the set it has
+    // just issued -- because it cannot count LDS returns across the loop back edge; wait_frags counts them instead
+    const uint32_t aa = (uint32_t)(size_t)(st + ((wm * R) * 32 + r) * 64 + pos - lds);
+    const uint32_t ab = (uint32_t)(size_t)(st + (TM + (wn * QB) * 32 + r) * 64 + pos - lds);
+#pragma unroll
+    for (int b = 0; b < R; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][b]) : "v"(aa), "n"(b * 2048));
+#pragma unroll
+    for (int q = 0; q < QB; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][q]) : "v"(ab), "n"(q * 2048));
+  };
+  // the fragments of `set` have arrived when at most R + QB younger LDS reads (the other set's) are outstanding: LDS
+  // returns in order
+  auto wait_frags = [&](int set) __attribute__((always_inline)) {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R + QB) : "memory");
+#pragma unroll
+    for (int b = 0; b < R; ++b) asm volatile("" : "+v"(fa[set][b]));  // (the MFMAs below depend on this point)
+#pragma unroll
+    for (int q = 0; q < QB; ++q) asm volatile("" : "+v"(fb[set][q]));
+  };
+  auto mfmas = [&](int set, bool first) __attribute__((always_inline)) {  // first: a tile's first k-step starts from C = 0
+#pragma unroll
+    for (int q = 0; q < QB; ++q)
+#pragma unroll
+      for (int b = 0; b < R; ++b) {
+#if defined(AP_ABLATE) && AP_ABLATE == 1
+        asm volatile("" ::"v"(fa[set][b]), "v"(fb[set][q]));
+        continue;
+#endif
+        const f32x16 c = first ? (f32x16)(0.0f) : acc[b][q];
+        if constexpr (DT == MAXSIM_F16)
+          acc[b][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][b]), __builtin_bit_cast(f16x8, fb[set][q]), c, 0, 0, 0);
+        else
+          acc[b][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][b]), __builtin_bit_cast(bf16x8, fb[set][q]), c, 0, 0, 0);
+      }
+  };
+
+  // masks (float32 or none -- the launcher sends other mask types to the streaming kernel): the tile's mask rows come in
+  // by LDS-DMA with the tile's first slices, like everything else.  An ordinary load anywhere in this loop would make the
+  // compiler wait for its result with s_waitcnt vmcnt(0), i.e. for every slice in flight: the ring would never run ahead
+  // (measured: that alone held the kernel at 35 % MFMA busy).
+  const bool masked = a.mask_dtype != MAXSIM_MASK_NONE;
+  // rows past Ld are tile padding: their mask word is NaN for the whole kernel, so their products are NaN and never win a
+  // `>` (no bound test per element in the epilogue); without masks every real row / token weighs 1
+  for (int i = tid; i < TM + NQ * 32; i += 512) {
+    const bool pad = i >= a.Ld && i < TM;
+    if (pad || !masked) dm_lds[i] = pad ? __builtin_nanf("") : 1.0f;
+  }
+  auto issue_masks = [&](int ti) __attribute__((always_inline)) {  // waves 6 and 7, after their part of a tile's first slice
+    const int u = l + ti * nl;
+    const int d = tile_doc(u), q0 = tile_q0(u);
+    if (wave == 6) {
+#pragma unroll
+      for (int j = 0; j < TM / 64; ++j) {
+        const int row = j * 64 + lane;
+        if (row < a.Ld)  // (lanes past Ld stay out: their words keep the NaN)
+          __builtin_amdgcn_global_load_lds(GPTR((const float*)a.d_mask + (int64_t)d * a.Ld + row), (__attribute__((address_space(3))) void*)(dm_dst + j * 256), 4, 0, 0);
+      }
+    } else if (wave == 7) {
+#pragma unroll
+      for (int j = 0; j < NQ / 2; ++j) {
+        const int slot = 2 * j + (lane >> 5);
+        const int qq = min(q0 + slot, a.nq - 1), t = min(lane & 31, a.Lq - 1);  // past nq / Lq: any valid word (weight 0 below)
+        __builtin_amdgcn_global_load_lds(GPTR((const float*)a.q_mask + (int64_t)qq * a.Lq + t), (__attribute__((address_space(3))) void*)(qm_dst + j * 256), 4, 0, 0);
+      }
+    }
+  };
+  if (total > 0) issue(0);
+  if (total > 1) issue(1);
+  if (total > 2) issue(2);
+  if (total > 0 && masked) issue_masks(0);
+  if (total > 0) {  // slice 0 for everybody, its first fragments on their way
+    if (masked && wave >= 6) wait_vmcnt<0>();  // (their mask rows sit behind the slices in the queue: once, at start)
+    else if (total > 2) { if (my_ndma == NMAX) wait_vmcnt<2 * NMAX>(); else wait_vmcnt<2 * NMAX - 2>(); }
+    else if (total > 1) { if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>(); }
+    else wait_vmcnt<0>();
+    wg_barrier();
+    load_frags(0, 0, 0);
+  }
+
+  int ti = 0, s = -1;
+  for (int g = 0; g < total; ++g) {
+    if (++s == nslices) { s = 0; ++ti; }
+    // slice g + 1 has landed: this wave's part (counted: the instructions of slice g + 2 may still be in flight.  Loads retire
+    // in order, so "at most my_ndma outstanding" implies slice g + 1 is in whatever the epilogue's younger stores and the
+    // mask rows are doing: at worst the wait runs a few instructions into slice g + 2), then everybody's.  The barrier also
+    // says: every wave is done reading slice g - 1, whose stage slice g + 3 overwrites.
+    if (g + 2 >= total) wait_vmcnt<0>(); else if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>();
+    wg_barrier();
+    if (g + 3 < total) issue(g + 3);
+    if (masked && s == 0 && g > 0) issue_masks(ti);  // (tile 0's were issued in the prologue)
+    // (scheduling fences: left alone the compiler sinks the fragment reads next to their first use and waits for them
+    //  at once, which re-serialises the LDS and MFMA phases)
+    load_frags(1, g, 1);
+    wait_frags(0);      // set 0 (requested one k-step ago) is in; set 1 may still be on its way
+    __builtin_amdgcn_sched_barrier(0);
+    if (s == 0) mfmas(0, true); else mfmas(0, false);
+    __builtin_amdgcn_sched_barrier(0);
+    load_frags(0, g + 1, 0);  // (unconditional: past the last slice it reads a stale stage and the result is dropped)
+    wait_frags(1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfmas(1, false);
+    __builtin_amdgcn_sched_barrier(0);
+    if (s + 1 < nslices) continue;
+#if defined(AP_ABLATE) && AP_ABLATE == 5  // (diagnostic builds: no epilogue)
+    continue;
+#endif
+
+    // ---- epilogue of tile ti: similarities complete ----------------------------------------------------------------
+    const int u = l + ti * nl;
+    const int d = tile_doc(u), q0 = tile_q0(u);
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {  // one query at a time: the accumulators leave few registers for anything else
+      const int qq = q0 + wn * QB + q;
+      // tokens past Lq and query slots past nq: weight 0 (similarity 0, nothing written)
+      const float qm = (qq < a.nq && r < a.Lq) ? qm_lds[(wn * QB + q) * 32 + r] : 0.0f;
+      float best = NEG_INF;
+      int bidx = 0;
+#pragma unroll
+      for (int b = 0; b < R; ++b) {
+        int rowbase = (wm * R + b) * 32 + 4 * hh;
+        asm volatile("" : "+v"(rowbase));  // opaque: otherwise the row numbers / mask words are shared by the QB unrolled
+                                           // query iterations and stay live across all of them (registers)
+        // d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait (a read + wait per pair of
+        // rows made the epilogue cost as much as the whole K loop: 14 us per tile)
+        f32x4 d4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm_lds + rowbase + 8 * k);  // NaN past Ld (tile padding)
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {  // rows in increasing order, two at a time (v_pk_mul_f32)
+          const int row = rowbase + (v & 3) + 8 * (v >> 2);
+          f32x2 w = {d4[v >> 2][v & 3], d4[v >> 2][(v & 3) + 1]};
+          w *= qm;
+          f32x2 sim = {acc[b][q][v], acc[b][q][v + 1]};
+          sim *= w;                                            // (Q q_mask) . (D d_mask), BaseModel.py:41-43
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            const bool better = sim[e] > best;                 // strict >: the first maximal token wins (torch.max);
+            best = better ? sim[e] : best;                     // a NaN (row past Ld) never does
+            if (AM) bidx = better ? row + e : bidx;
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (one block's mask words at a time)
+      }
+      // the two lane halves hold interleaved rows of the same query token
+      const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
+      const float va = __uint_as_float(sv[0]), vb = __uint_as_float(sv[1]);
+      float v2;
+      int i2 = 0;
+      if constexpr (AM) {
+        const auto si = __builtin_amdgcn_permlane32_swap((uint32_t)bidx, (uint32_t)bidx, false, false);
+        const int ia = (int)si[0], ib = (int)si[1];
+        const bool take_b = (vb > va) || (vb == va && ib < ia);
+        v2 = take_b ? vb : va;
+        i2 = take_b ? ib : ia;
+      } else {
+        v2 = fmaxf(va, vb);
+      }
+      if (lane < 32) {
+        ex_v[((wn * QB + q) * 4 + wm) * 32 + lane] = v2;
+        if (AM) ex_i[((wn * QB + q) * 4 + wm) * 32 + lane] = i2;
+      }
+    }
+    lds_barrier();
+    // the row-waves' results meet: wave w finishes query slot w of the tile (NQ <= 8 slots)
+    if (wave < NQ) {
+      const int qq = q0 + wave;
+      float best = NEG_INF;
+      int bidx = 0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {  // increasing row ranges: strict > keeps the first maximal token
+        const float v = ex_v[(wave * 4 + w) * 32 + r];
+        const bool better = v > best;
+        best = better ? v : best;
+        if (AM) bidx = better ? ex_i[(wave * 4 + w) * 32 + r] : bidx;
+      }
+      if (qq < a.nq) {
+        if (AM && lane < a.Lq) a.argmax[((int64_t)qq * a.nd + d) * a.Lq + lane] = bidx;
+        float v = best;  // both lane halves hold the 32 tokens: sum one half with a fixed DPP tree
+        v += ap_dpp<0xB1>(v);
+        v += ap_dpp<0x4E>(v);
+        v += ap_dpp<0x141>(v);
+        v += ap_dpp<0x140>(v);
+        const float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+                         __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+        if (lane == 0) a.scores[(int64_t)qq * a.nd + d] = sc;
+      }
+    }
+    // (the exchange area is rewritten only after the next tile's slices, i.e. after many more barriers)
+  }
+}
+
+}  // namespace maxsim

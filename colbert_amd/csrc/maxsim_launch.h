@@ -90,5 +90,7 @@ int launch_stream_small(Params& p, int index_dtype, hipStream_t st);
 // Return MAXSIM_ERANGE when the query image does not fit in LDS.
 int launch_bigh_rerank(Params& p, int dt, hipStream_t st);
 int launch_bigh_dense(Params& p, int dt, bool argmax, hipStream_t st);
+// tu_allpairs.hip: the GEMM-blocked all-pairs kernel (16-bit operands, Lq <= 32, Ld <= 384); MAXSIM_ERANGE = not its shape.
+int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st);
 
 }  // namespace maxsim

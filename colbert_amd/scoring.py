@@ -37,6 +37,10 @@ def _prepare(Q, D, q_mask, d_mask):
     Qc = Q.detach().to(device=dev, dtype=cdt).contiguous()
     Dc = D.detach().to(device=dev, dtype=cdt).contiguous()
     mdt = d_mask.dtype if d_mask.dtype in _MDT else torch.float32
+    if cdt != torch.float32:
+        # the GEMM-blocked all-pairs kernel (16-bit operands) takes its mask rows by LDS-DMA as float words: hand the masks
+        # over as float32 (the reference's int64 0/1 masks convert exactly; the kernels compute with float masks anyway)
+        mdt = torch.float32
     qm = q_mask.to(device=dev, dtype=mdt).contiguous()
     dm = d_mask.to(device=dev, dtype=mdt).contiguous()
     return Qc, Dc, qm, dm, cdt, mdt, out_dtype

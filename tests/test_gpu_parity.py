@@ -600,6 +600,11 @@ def test_fp32_fast_mode(ca, golden):
     dict(nq=2, Lq=40, nd=2, Ld=9, h=128, dtype=torch.float32, masks="none"),       # Lq > 32: generic kernel
     dict(nq=70, Lq=3, nd=130, Ld=5, h=200, dtype=torch.float32, masks="01"),       # > 64 docs / items per lane batch
     dict(nq=1, Lq=2, nd=1, Ld=700, h=64, dtype=torch.float32, masks="none"),       # long doc: atomic dD fallback
+    # enough (doc, query block) tiles for the GEMM-blocked all-pairs kernel (maxsim_allpairs.h), its three row-block forms
+    dict(nq=20, Lq=32, nd=70, Ld=384, h=64, dtype=torch.bfloat16, masks="01"),      # R = 3 (doc_maxlen), partial query block
+    dict(nq=17, Lq=20, nd=66, Ld=200, h=128, dtype=torch.float16, masks="01"),      # R = 2, rows past Ld, Lq < 32
+    dict(nq=24, Lq=32, nd=50, Ld=100, h=768, dtype=torch.bfloat16, masks="none"),   # R = 1, the reference's dim
+    dict(nq=9, Lq=7, nd=131, Ld=333, h=96, dtype=torch.float16, masks="01"),        # odd everything
 ])
 def test_score_autograd_matches_torch(ca, cfg):
     from oracle.maxsim_oracle import ref_score
@@ -633,9 +638,11 @@ def test_score_autograd_matches_torch(ca, cfg):
     D2 = D0.detach().cuda().requires_grad_(True)
     (ca.score(Q0.cuda(), D2, qm.cuda(), dm.cuda()).float() * w.cuda()).sum().backward()
     torch.testing.assert_close(D2.grad.float().cpu(), Dr.grad, rtol=0, atol=tol)
-    # no_grad: plain forward
+    # no_grad: plain forward (no arg-max), same values
     with torch.no_grad():
-        assert not ca.score(Qg, Dg, qm.cuda(), dm.cuda()).requires_grad
+        plain = ca.score(Qg, Dg, qm.cuda(), dm.cuda())
+        assert not plain.requires_grad
+        torch.testing.assert_close(plain.float().cpu(), out_g.detach().float().cpu(), rtol=0, atol=1e-5 if cfg["dtype"] == torch.float32 else 2e-2)
 
 
 # ------------------------------------------------------------------------------------------------------
