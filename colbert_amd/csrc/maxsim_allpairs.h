@@ -15,9 +15,13 @@
 //   wave       R row blocks x QB queries of 32x32x16 MFMAs: R + QB fragment reads (1 KB each) per R QB MFMAs, 16 R QB
 //              accumulator registers.  (R, QB) = (1, 4), (2, 4), (3, 3): with 8 waves a wave has 256 registers, and
 //              3 x 4 blocks (192 accumulators) spilled; 3 x 3 = 0.67 KB of LDS reads per MFMA
-//   K          sliced by 32 dims: a slice is (128 R + 256) rows x 64 B, fetched by LDS-DMA (global_load_lds_dwordx4,
-//              no register staging) into a 3-stage ring: ONE workgroup barrier per slice, two slices in flight
-//   tiles      workgroups are persistent (one per CU: 120 KB of LDS) and walk (doc, query block) tiles; the ring runs
+//   K          sliced by 32 dims: a slice is (128 R + 64 QB) rows x 64 B, fetched by LDS-DMA (global_load_lds_dwordx4, no
+//              register staging; source addresses = wave-uniform 64-bit base + a 32-bit lane offset computed once) into a
+//              4-stage ring: slice g being read, g + 1 complete (its first fragments are requested across the barrier),
+//              g + 2 and g + 3 in flight.  ONE bare s_barrier per slice (__syncthreads would wait for every DMA in
+//              flight), counted s_waitcnt vmcnt for the slice that must have landed; fragment reads are ds_read_b128 by
+//              hand, double-buffered, placed between the MFMAs of the previous k-step
+//   tiles      workgroups are persistent (one per CU: ~150 KB of LDS) and walk (doc, query block) tiles; the ring runs
 //              across tile boundaries, so the next tile's first slices arrive during the epilogue.  XCD x takes the docs
 //              x, x + 8, ... and walks their query blocks in order: the ~32 workgroups of an XCD work on one or two docs at
 //              a time (the doc comes from that XCD's L2; the 13 MB of queries from the Infinity Cache)
@@ -148,11 +152,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
         const int lr = 16 * ins + (lane >> 2);
         g_ptr = qbase + (((lr - TM) >> 5) < is_nvalid ? off[j] : off0[j]);   // slots past nq re-read slot 0
       }
-#if !defined(AP_ABLATE) || AP_ABLATE != 2  // (diagnostic builds: -DAP_ABLATE=1 no MFMA, 2 no DMA, 3 no fragment reads)
       __builtin_amdgcn_global_load_lds(GPTR(g_ptr), LPTR(dst + j * 8192), 16, 0, 0);
-#else
-      asm volatile("" ::"v"(g_ptr));
-#endif
     }
     if (++is_s == nslices) { is_s = 0; ++is_ti; }
   };
@@ -170,19 +170,9 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   // LDS (a workgroup's waves hit the barrier together; without this overlap the LDS read phase -- 96 KB per slice and CU,
   // 768 cycles at 128 B/clk -- and the MFMA phase -- 1152 cycles per SIMD -- serialise: measured 35 % MFMA busy)
   u32x4 fa[2][R], fb[2][QB];
-#if defined(AP_ABLATE) && AP_ABLATE == 3
-  for (int i = 0; i < 2; ++i) {
-    for (int b = 0; b < R; ++b) fa[i][b] = (u32x4)(0x3f803f80u);
-    for (int q = 0; q < QB; ++q) fb[i][q] = (u32x4)(0x3f803f80u);
-  }
-#endif
   auto load_frags = [&](int set, int g, int ks) __attribute__((always_inline)) {
     const char* const st = lds + (g % NST) * STAGE;
     const int pos = ((2 * ks + hh) ^ swz) * 16;
-#if defined(AP_ABLATE) && AP_ABLATE == 3
-    asm volatile("" ::"v"(st), "v"(pos));
-    return;
-#endif
     // ds_read_b128 by hand: the compiler would wait for a set with s_waitcnt lgkmcnt(0) -- i.e. also for the set it has
     // just issued -- because it cannot count LDS returns across the loop back edge; wait_frags counts them instead
     const uint32_t aa = (uint32_t)(size_t)(st + ((wm * R) * 32 + r) * 64 + pos - lds);
@@ -192,32 +182,14 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
 #pragma unroll
     for (int q = 0; q < QB; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][q]) : "v"(ab), "n"(q * 2048));
   };
-  // the fragments of `set` have arrived when at most R + QB younger LDS reads (the other set's) are outstanding: LDS
-  // returns in order
+  // every LDS read issued so far has returned (the reads of a set are issued a whole k-step before they are needed)
   auto wait_frags = [&](int set) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(R + QB) : "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int b = 0; b < R; ++b) asm volatile("" : "+v"(fa[set][b]));  // (the MFMAs below depend on this point)
 #pragma unroll
     for (int q = 0; q < QB; ++q) asm volatile("" : "+v"(fb[set][q]));
   };
-  auto mfmas = [&](int set, bool first) __attribute__((always_inline)) {  // first: a tile's first k-step starts from C = 0
-#pragma unroll
-    for (int q = 0; q < QB; ++q)
-#pragma unroll
-      for (int b = 0; b < R; ++b) {
-#if defined(AP_ABLATE) && AP_ABLATE == 1
-        asm volatile("" ::"v"(fa[set][b]), "v"(fb[set][q]));
-        continue;
-#endif
-        const f32x16 c = first ? (f32x16)(0.0f) : acc[b][q];
-        if constexpr (DT == MAXSIM_F16)
-          acc[b][q] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][b]), __builtin_bit_cast(f16x8, fb[set][q]), c, 0, 0, 0);
-        else
-          acc[b][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][b]), __builtin_bit_cast(bf16x8, fb[set][q]), c, 0, 0, 0);
-      }
-  };
-
   // masks (float32 or none -- the launcher sends other mask types to the streaming kernel): the tile's mask rows come in
   // by LDS-DMA with the tile's first slices, like everything else.  An ordinary load anywhere in this loop would make the
   // compiler wait for its result with s_waitcnt vmcnt(0), i.e. for every slice in flight: the ring would never run ahead
@@ -270,24 +242,93 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     // says: every wave is done reading slice g - 1, whose stage slice g + 3 overwrites.
     if (g + 2 >= total) wait_vmcnt<0>(); else if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>();
     wg_barrier();
-    if (g + 3 < total) issue(g + 3);
-    if (masked && s == 0 && g > 0) issue_masks(ti);  // (tile 0's were issued in the prologue)
-    // (scheduling fences: left alone the compiler sinks the fragment reads next to their first use and waits for them
-    //  at once, which re-serialises the LDS and MFMA phases)
-    load_frags(1, g, 1);
-    wait_frags(0);      // set 0 (requested one k-step ago) is in; set 1 may still be on its way
-    __builtin_amdgcn_sched_barrier(0);
-    if (s == 0) mfmas(0, true); else mfmas(0, false);
-    __builtin_amdgcn_sched_barrier(0);
-    load_frags(0, g + 1, 0);  // (unconditional: past the last slice it reads a stale stage and the result is dropped)
+    // One slice = two k-steps of R QB MFMAs.  A wave issues at most one instruction every 4 cycles, and an MFMA keeps the
+    // matrix pipe busy for 32: everything else the wave has to do per slice (fragment reads, LDS-DMA issue with its
+    // scalar address arithmetic, loop control: ~230 instructions = ~1000 cycles, measured with the MFMAs and all memory
+    // instructions taken out) must sit BETWEEN its MFMAs in program order, or -- the workgroup's waves being in the same
+    // phase after every barrier -- it simply adds to the 1152 cycles of MFMA time (2.9 ms, 37 % of peak).
+    constexpr int NM = R * QB, NF = R + QB;
+    constexpr int SLOTS = NM > NF ? NM - NF : 1, PER = (NMAX + SLOTS - 1) / SLOTS;  // DMA instructions per late MFMA
+    const bool do_issue = g + 3 < total;
+    const bool first = s == 0;
+    char* dma_dst = nullptr;
+    const char *dma_db = nullptr, *dma_qb = nullptr;
+    if (do_issue) {
+      if (is_s == 0) issue_tile_setup();
+      dma_dst = lds + ((g + 3) % NST) * STAGE + wave * 1024;
+      dma_db = is_dbase + is_s * 64;
+      dma_qb = is_qbase + is_s * 64;
+      if (++is_s == nslices) { is_s = 0; ++is_ti; }
+    }
+#define AP_DMA(j)                                                                                                     \
+  do {                                                                                                                \
+    const int ins_ = wave + 8 * (j);                                                                                  \
+    if (ins_ < NI) {                                                                                                  \
+      const char* gp_;                                                                                                \
+      if (ins_ < NAI) gp_ = dma_db + off[j];                                                                          \
+      else gp_ = dma_qb + ((((16 * ins_ + (lane >> 2)) - TM) >> 5) < is_nvalid_cur ? off[j] : off0[j]);             \
+      __builtin_amdgcn_global_load_lds(GPTR(gp_), LPTR(dma_dst + (j) * 8192), 16, 0, 0);                            \
+    }                                                                                                                 \
+  } while (0)
+#define AP_MFMA(set, i, c0)                                                                                           \
+  do {                                                                                                                \
+    const int q_ = (i) / R, b_ = (i) % R;                                                                             \
+    const f32x16 c_ = (c0) ? (f32x16)(0.0f) : acc[b_][q_];                                                            \
+    if constexpr (DT == MAXSIM_F16)                                                                                   \
+      acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][b_]), __builtin_bit_cast(f16x8, fb[set][q_]), c_, 0, 0, 0); \
+    else                                                                                                              \
+      acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][b_]), __builtin_bit_cast(bf16x8, fb[set][q_]), c_, 0, 0, 0); \
+  } while (0)
+    const int is_nvalid_cur = is_nvalid;
+    // fragment addresses: (g, k-step 1) for set 1, (g + 1, k-step 0) for set 0 (past the last slice: a stale stage, dropped)
+    const uint32_t st1 = (uint32_t)((g % NST) * STAGE), st0 = (uint32_t)(((g + 1) % NST) * STAGE);
+    const uint32_t pos1 = (uint32_t)(((2 + hh) ^ swz) * 16), pos0 = (uint32_t)((hh ^ swz) * 16);
+    const uint32_t a1 = st1 + ((wm * R) * 32 + r) * 64 + pos1, b1 = st1 + (TM + (wn * QB) * 32 + r) * 64 + pos1;
+    const uint32_t a0 = st0 + ((wm * R) * 32 + r) * 64 + pos0, b0 = st0 + (TM + (wn * QB) * 32 + r) * 64 + pos0;
+    wait_frags(0);  // set 0 (requested during the previous k-step) is in: no younger LDS read is outstanding here
+    if (masked && first && g > 0) issue_masks(ti);  // (tile 0's were issued in the prologue)
+    // ---- k-step 0: MFMAs on set 0, between them the reads of set 1, then the LDS-DMA instructions of slice g + 3
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      if (first) AP_MFMA(0, i, true); else AP_MFMA(0, i, false);
+      if (i < R) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < R ? i : 0]) : "v"(a1), "n"(i * 2048));
+      } else if (i < NF) {
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= R && i < NF ? i - R : 0]) : "v"(b1), "n"((i - R) * 2048));
+      } else if (do_issue) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+          const int j = (i - NF) * PER + t;
+          if (j < NMAX) AP_DMA(j < NMAX ? j : 0);
+        }
+      }
+    }
+    // (what did not fit between the MFMAs: R QB < R + QB happens for R = 1)
+#pragma unroll
+    for (int i = NM; i < NF; ++i) {
+      if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < R ? i : 0]) : "v"(a1), "n"(i * 2048));
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= R && i < NF ? i - R : 0]) : "v"(b1), "n"((i - R) * 2048));
+    }
+    if (NM <= NF && do_issue) {
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j) AP_DMA(j);
+    }
     wait_frags(1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfmas(1, false);
-    __builtin_amdgcn_sched_barrier(0);
+    // ---- k-step 1: MFMAs on set 1, between them the reads of the next slice's set 0
+#pragma unroll
+    for (int i = 0; i < NM; ++i) {
+      AP_MFMA(1, i, false);
+      if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < R ? i : 0]) : "v"(a0), "n"(i * 2048));
+      else if (i < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= R && i < NF ? i - R : 0]) : "v"(b0), "n"((i - R) * 2048));
+    }
+#pragma unroll
+    for (int i = NM; i < NF; ++i) {
+      if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < R ? i : 0]) : "v"(a0), "n"(i * 2048));
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= R && i < NF ? i - R : 0]) : "v"(b0), "n"((i - R) * 2048));
+    }
+#undef AP_DMA
+#undef AP_MFMA
     if (s + 1 < nslices) continue;
-#if defined(AP_ABLATE) && AP_ABLATE == 5  // (diagnostic builds: no epilogue)
-    continue;
-#endif
 
     // ---- epilogue of tile ti: similarities complete ----------------------------------------------------------------
     const int u = l + ti * nl;
