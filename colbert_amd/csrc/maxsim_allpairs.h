@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     const int ins = wave + 8 * j;
     const int lr = 16 * ins + (lane >> 2);
     const uint32_t chunk = (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) * 16);
-    if (ins < NAI) {
+    if (j < R) {
       off[j] = (uint32_t)(min(lr, a.Ld - 1) * (int)rowb) + chunk;  // rows past Ld re-read the last row (never candidates)
       off0[j] = 0;
     } else {
@@ -146,7 +146,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       const int ins = wave + 8 * j;                                           // wave-uniform
       if (ins >= NI) break;
       const char* g_ptr;
-      if (ins < NAI) {
+      if (j < R) {                                                            // (doc rows = the first 8 R instructions)
         g_ptr = dbase + off[j];
       } else {
         const int lr = 16 * ins + (lane >> 2);
@@ -233,40 +233,75 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     load_frags(0, 0, 0);
   }
 
-  int ti = 0, s = -1;
+  // Per-iteration bookkeeping (loop position, which wait, the LDS-DMA bases of slice g + 3, fragment addresses): ~100 scalar
+  // and vector instructions.  A wave issues at most one instruction every 4 cycles, an MFMA keeps the matrix pipe busy for
+  // 32, and after every barrier all eight waves are in the same phase: whatever is not placed BETWEEN a wave's MFMAs in
+  // program order adds to the 1152 cycles of MFMA time per slice instead of hiding under it (measured: the loop skeleton
+  // alone, with the MFMAs and every memory instruction taken out, cost 1040 cycles per slice).  So the state of
+  // iteration g + 1 is prepared in the middle of iteration g's second k-step.
+  struct Step {
+    int s, ti;
+    bool first, do_issue, do_masks, vm_all;
+    char* dma_dst;
+    const char *dma_db, *dma_qb;
+    int nvalid;
+    uint32_t a1, b1, a0, b0;
+  };
+  int lp_s = -1, lp_ti = 0;
+  auto prep = [&](int g) __attribute__((always_inline)) -> Step {
+    Step t;
+    if (++lp_s == nslices) { lp_s = 0; ++lp_ti; }
+    t.s = lp_s;
+    t.ti = lp_ti;
+    t.first = lp_s == 0;
+    t.do_issue = g + 3 < total;
+    t.do_masks = masked && t.first && g > 0;  // (tile 0's mask rows are issued in the prologue)
+    t.vm_all = g + 2 >= total;
+    t.dma_dst = nullptr;
+    t.dma_db = t.dma_qb = nullptr;
+    if (t.do_issue) {
+      if (is_s == 0) issue_tile_setup();
+      t.dma_dst = lds + ((g + 3) % NST) * STAGE + wave * 1024;
+      t.dma_db = is_dbase + is_s * 64;
+      t.dma_qb = is_qbase + is_s * 64;
+      if (++is_s == nslices) { is_s = 0; ++is_ti; }
+    }
+    t.nvalid = is_nvalid;
+    // fragment addresses: (g, k-step 1) for set 1, (g + 1, k-step 0) for set 0 (past the last slice: a stale stage, dropped)
+    const uint32_t st1 = (uint32_t)((g % NST) * STAGE), st0 = (uint32_t)(((g + 1) % NST) * STAGE);
+    const uint32_t pos1 = (uint32_t)(((2 + hh) ^ swz) * 16), pos0 = (uint32_t)((hh ^ swz) * 16);
+    t.a1 = st1 + ((wm * R) * 32 + r) * 64 + pos1;
+    t.b1 = st1 + (TM + (wn * QB) * 32 + r) * 64 + pos1;
+    t.a0 = st0 + ((wm * R) * 32 + r) * 64 + pos0;
+    t.b0 = st0 + (TM + (wn * QB) * 32 + r) * 64 + pos0;
+    return t;
+  };
+  Step cur = prep(0);
   for (int g = 0; g < total; ++g) {
-    if (++s == nslices) { s = 0; ++ti; }
+    const int s = cur.s, ti = cur.ti;
     // slice g + 1 has landed: this wave's part (counted: the instructions of slice g + 2 may still be in flight.  Loads retire
     // in order, so "at most my_ndma outstanding" implies slice g + 1 is in whatever the epilogue's younger stores and the
     // mask rows are doing: at worst the wait runs a few instructions into slice g + 2), then everybody's.  The barrier also
     // says: every wave is done reading slice g - 1, whose stage slice g + 3 overwrites.
-    if (g + 2 >= total) wait_vmcnt<0>(); else if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>();
+    if (cur.vm_all) wait_vmcnt<0>(); else if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>();
     wg_barrier();
-    // One slice = two k-steps of R QB MFMAs.  A wave issues at most one instruction every 4 cycles, and an MFMA keeps the
-    // matrix pipe busy for 32: everything else the wave has to do per slice (fragment reads, LDS-DMA issue with its
-    // scalar address arithmetic, loop control: ~230 instructions = ~1000 cycles, measured with the MFMAs and all memory
-    // instructions taken out) must sit BETWEEN its MFMAs in program order, or -- the workgroup's waves being in the same
-    // phase after every barrier -- it simply adds to the 1152 cycles of MFMA time (2.9 ms, 37 % of peak).
+    // One slice = two k-steps of R QB MFMAs, with the R + QB fragment reads of the next k-step and the LDS-DMA
+    // instructions of slice g + 3 between them.
     constexpr int NM = R * QB, NF = R + QB;
     constexpr int SLOTS = NM > NF ? NM - NF : 1, PER = (NMAX + SLOTS - 1) / SLOTS;  // DMA instructions per late MFMA
-    const bool do_issue = g + 3 < total;
-    const bool first = s == 0;
-    char* dma_dst = nullptr;
-    const char *dma_db = nullptr, *dma_qb = nullptr;
-    if (do_issue) {
-      if (is_s == 0) issue_tile_setup();
-      dma_dst = lds + ((g + 3) % NST) * STAGE + wave * 1024;
-      dma_db = is_dbase + is_s * 64;
-      dma_qb = is_qbase + is_s * 64;
-      if (++is_s == nslices) { is_s = 0; ++is_ti; }
-    }
+    const bool do_issue = cur.do_issue;
+    const bool first = cur.first;
+    char* const dma_dst = cur.dma_dst;
+    const char* const dma_db = cur.dma_db;
+    const char* const dma_qb = cur.dma_qb;
+// LDS-DMA instruction j of this wave: image rows 16 (wave + 8 j) ...  The doc rows are the first 8 R instructions, so
+// "doc or query rows" depends on j alone; only the last j can fall off the end of the image (runtime test on the wave)
 #define AP_DMA(j)                                                                                                     \
   do {                                                                                                                \
-    const int ins_ = wave + 8 * (j);                                                                                  \
-    if (ins_ < NI) {                                                                                                  \
+    if ((j) < NI / 8 || wave < NI - 8 * (j)) {                                                                        \
       const char* gp_;                                                                                                \
-      if (ins_ < NAI) gp_ = dma_db + off[j];                                                                          \
-      else gp_ = dma_qb + ((((16 * ins_ + (lane >> 2)) - TM) >> 5) < is_nvalid_cur ? off[j] : off0[j]);             \
+      if ((j) < R) gp_ = dma_db + off[j];                                                                             \
+      else gp_ = dma_qb + ((((16 * (wave + 8 * (j)) + (lane >> 2)) - TM) >> 5) < is_nvalid_cur ? off[j] : off0[j]);  \
       __builtin_amdgcn_global_load_lds(GPTR(gp_), LPTR(dma_dst + (j) * 8192), 16, 0, 0);                            \
     }                                                                                                                 \
   } while (0)
@@ -279,14 +314,10 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     else                                                                                                              \
       acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][b_]), __builtin_bit_cast(bf16x8, fb[set][q_]), c_, 0, 0, 0); \
   } while (0)
-    const int is_nvalid_cur = is_nvalid;
-    // fragment addresses: (g, k-step 1) for set 1, (g + 1, k-step 0) for set 0 (past the last slice: a stale stage, dropped)
-    const uint32_t st1 = (uint32_t)((g % NST) * STAGE), st0 = (uint32_t)(((g + 1) % NST) * STAGE);
-    const uint32_t pos1 = (uint32_t)(((2 + hh) ^ swz) * 16), pos0 = (uint32_t)((hh ^ swz) * 16);
-    const uint32_t a1 = st1 + ((wm * R) * 32 + r) * 64 + pos1, b1 = st1 + (TM + (wn * QB) * 32 + r) * 64 + pos1;
-    const uint32_t a0 = st0 + ((wm * R) * 32 + r) * 64 + pos0, b0 = st0 + (TM + (wn * QB) * 32 + r) * 64 + pos0;
+    const int is_nvalid_cur = cur.nvalid;
+    const uint32_t a1 = cur.a1, b1 = cur.b1, a0 = cur.a0, b0 = cur.b0;
     wait_frags(0);  // set 0 (requested during the previous k-step) is in: no younger LDS read is outstanding here
-    if (masked && first && g > 0) issue_masks(ti);  // (tile 0's were issued in the prologue)
+    if (cur.do_masks) issue_masks(ti);
     // ---- k-step 0: MFMAs on set 0, between them the reads of set 1, then the LDS-DMA instructions of slice g + 3
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
@@ -315,11 +346,13 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     }
     wait_frags(1);
     // ---- k-step 1: MFMAs on set 1, between them the reads of the next slice's set 0
+    Step nxt = cur;
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       AP_MFMA(1, i, false);
       if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < R ? i : 0]) : "v"(a0), "n"(i * 2048));
       else if (i < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= R && i < NF ? i - R : 0]) : "v"(b0), "n"((i - R) * 2048));
+      if (i == (NM > 2 ? 2 : NM - 1)) nxt = prep(g + 1);  // the next iteration's bookkeeping, under this k-step's MFMAs
     }
 #pragma unroll
     for (int i = NM; i < NF; ++i) {
@@ -328,7 +361,10 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     }
 #undef AP_DMA
 #undef AP_MFMA
-    if (s + 1 < nslices) continue;
+    if (s + 1 < nslices) {
+      cur = nxt;
+      continue;
+    }
 
     // ---- epilogue of tile ti: similarities complete ----------------------------------------------------------------
     const int u = l + ti * nl;
@@ -411,6 +447,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       }
     }
     // (the exchange area is rewritten only after the next tile's slices, i.e. after many more barriers)
+    cur = nxt;
   }
 }
 
