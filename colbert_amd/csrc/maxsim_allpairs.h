@@ -319,21 +319,23 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     wait_frags(0);  // set 0 (requested during the previous k-step) is in: no younger LDS read is outstanding here
     if (cur.do_masks) issue_masks(ti);
     // ---- k-step 0: MFMAs on set 0, between them the reads of set 1, then the LDS-DMA instructions of slice g + 3
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      if (first) AP_MFMA(0, i, true); else AP_MFMA(0, i, false);
-      if (i < R) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < R ? i : 0]) : "v"(a1), "n"(i * 2048));
-      } else if (i < NF) {
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= R && i < NF ? i - R : 0]) : "v"(b1), "n"((i - R) * 2048));
-      } else if (do_issue) {
-#pragma unroll
-        for (int t = 0; t < PER; ++t) {
-          const int j = (i - NF) * PER + t;
-          if (j < NMAX) AP_DMA(j < NMAX ? j : 0);
-        }
-      }
-    }
+    //      (two copies, so that "a tile's first k-step starts from C = 0" is ONE branch per slice, not one per MFMA)
+#define AP_KSTEP0(C0)                                                                                                 \
+  _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                                    \
+    AP_MFMA(0, i, C0);                                                                                                \
+    if (i < R) {                                                                                                      \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < R ? i : 0]) : "v"(a1), "n"(i * 2048));           \
+    } else if (i < NF) {                                                                                              \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= R && i < NF ? i - R : 0]) : "v"(b1), "n"((i - R) * 2048)); \
+    } else if (do_issue) {                                                                                            \
+      _Pragma("unroll") for (int t = 0; t < PER; ++t) {                                                               \
+        const int j = (i - NF) * PER + t;                                                                             \
+        if (j < NMAX) AP_DMA(j < NMAX ? j : 0);                                                                       \
+      }                                                                                                               \
+    }                                                                                                                 \
+  }
+    if (first) { AP_KSTEP0(true) } else { AP_KSTEP0(false) }
+#undef AP_KSTEP0
     // (what did not fit between the MFMAs: R QB < R + QB happens for R = 1)
 #pragma unroll
     for (int i = NM; i < NF; ++i) {
