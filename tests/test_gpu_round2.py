@@ -386,3 +386,54 @@ def test_topk_selection_with_heavy_ties(ca, ncand, k):
     es_k, ei = torch.sort(keys, dim=1, descending=True, stable=True)
     assert torch.equal(tp.cpu(), torch.gather(pids, 1, ei[:, :k]))
     assert torch.equal(ts.cpu().view(torch.int32), torch.gather(s, 1, ei[:, :k]).view(torch.int32))
+
+
+# ------------------------------------------------------------------------------------------------------
+# the GEMM-blocked all-pairs kernel (training-form forward) against the streaming kernel and the oracle
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(nq=50, nd=70, Lq=32, Ld=384, h=768, dtype=torch.bfloat16),     # the reference's training shape, R = 3
+    dict(nq=23, nd=41, Lq=32, Ld=256, h=128, dtype=torch.float16),      # R = 2 exactly full
+    dict(nq=16, nd=90, Lq=9, Ld=129, h=64, dtype=torch.bfloat16),       # R = 2, one row past 128
+    dict(nq=31, nd=33, Lq=32, Ld=128, h=32, dtype=torch.float16),       # R = 1, one K slice
+    dict(nq=8, nd=200, Lq=32, Ld=1, h=256, dtype=torch.bfloat16),       # one-token docs
+])
+def test_allpairs_kernel_matches_streaming_kernel_and_oracle(ca, cfg):
+    """maxsim_score_dense_fwd through the C ABI: float32 masks take the GEMM-blocked kernel (maxsim_allpairs.h), int64 masks
+    the streaming kernel (same values: 0/1).  Scores agree with each other and with the oracle on the rounded inputs
+    (1e-3: 16-bit inputs); arg-max indices are torch.max's (first maximal token) wherever the top two similarities of a
+    (query token, doc) pair are not within rounding of each other."""
+    from oracle.maxsim_oracle import ref_score
+    from colbert_amd.scoring import _DT, _MDT
+    L = ca._lib.lib
+    gen = torch.Generator().manual_seed(cfg["nq"] * 31 + cfg["Ld"])
+    nq, nd, Lq, Ld, h, dt = cfg["nq"], cfg["nd"], cfg["Lq"], cfg["Ld"], cfg["h"], cfg["dtype"]
+    Q = nrm(gen, nq, Lq, h).to(dt)
+    D = nrm(gen, nd, Ld, h).to(dt)
+    qm = (torch.rand(nq, Lq, generator=gen) > 0.15).long()
+    dm = (torch.rand(nd, Ld, generator=gen) > 0.25).long()
+    dm[:, 0] = 1
+    Qd, Dd = Q.cuda(), D.cuda()
+    res = {}
+    for name, mt in (("gemm", torch.float32), ("stream", torch.int64)):
+        qmd, dmd = qm.to(mt).cuda(), dm.to(mt).cuda()
+        out = torch.empty(nq, nd, device="cuda")
+        arg = torch.full((nq, nd, Lq), -7, dtype=torch.int32, device="cuda")
+        rc = L.maxsim_score_dense_fwd(Qd.data_ptr(), Dd.data_ptr(), qmd.data_ptr(), dmd.data_ptr(), nq, nd, Lq, Ld, h,
+                                      _DT[dt], _MDT[mt], out.data_ptr(), arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res[name] = (out.cpu(), arg.cpu())
+    exp = ref_score(Q.float(), D.float(), qm, dm)
+    torch.testing.assert_close(res["gemm"][0], exp, rtol=0, atol=ATOL16)
+    torch.testing.assert_close(res["gemm"][0], res["stream"][0], rtol=0, atol=ATOL16)
+    # arg-max against torch.max on the float64 similarities, skipping near-ties
+    sim = torch.einsum("qmh,dnh->qdmn", (Q.float() * qm[..., None]).double(), (D.float() * dm[..., None]).double())
+    top2 = sim.topk(min(2, Ld), dim=-1).values
+    clear = (top2[..., 0] - top2[..., -1] > 1e-4) if Ld > 1 else torch.ones(nq, nd, Lq, dtype=torch.bool)
+    ref_idx = sim.argmax(-1).to(torch.int32)
+    for name in ("gemm", "stream"):
+        got = res[name][1]
+        assert bool((got >= 0).all()) and bool((got < Ld).all()), name
+        assert bool((got[clear] == ref_idx[clear]).all()), name
+    assert float(clear.float().mean()) > 0.5
