@@ -41,7 +41,32 @@ struct AllPairsArgs {
   float* scores;       // [nq, nd]
   int32_t* argmax;     // [nq, nd, Lq] (AM)
   int mask_dtype, nq, nd, Lq, Ld, h;
+#ifdef MAXSIM_DIAG
+  int stamp_g0, stamp_wg;  // diagnostic build: s_memtime stamps of slices stamp_g0 .. + 23 of workgroup stamp_wg
+#endif
 };
+
+#ifdef MAXSIM_DIAG
+// In-kernel stamps (diagnostic build only; tools/allpairs_stamps.py reads them): [2 waves][24 slices][9 points].
+// A stamp is ONE scalar instruction whose result is not waited for (a wait would also drain the LDS reads in flight).
+// The nine results of a slice -- the ninth is the top of the NEXT iteration -- are stored right after that top stamp, so
+// the cost of storing them falls into the first segment of the next slice (top -> vmcnt wait) and nowhere else.  Kept in
+// LDS while the loop runs (a global store would count in vmcnt and move the loop's counted waits), dumped at the end.
+__device__ uint64_t g_ap_stamps[2 * 24 * 9];
+#define AP_STAMP(k) asm volatile("s_memtime %0" : "=s"(tS[k]))
+#define AP_STAMP_TOP()                                                                           \
+  do {                                                                                           \
+    AP_STAMP(8);                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
+    if (stamp_w >= 0 && g > a.stamp_g0 && g <= a.stamp_g0 + 24 && lane < 9)                      \
+      st_lds[(stamp_w * 24 + (g - 1 - a.stamp_g0)) * 9 + lane] = lane == 0 ? tS[0] : lane == 1 ? tS[1] : lane == 2 ? tS[2] : lane == 3 ? tS[3] : lane == 4 ? tS[4] : lane == 5 ? tS[5] : lane == 6 ? tS[6] : lane == 7 ? tS[7] : tS[8]; \
+    tS[0] = tS[8];                                                                               \
+    tS[7] = 0;                                                                                   \
+  } while (0)
+#else
+#define AP_STAMP(k) do {} while (0)
+#define AP_STAMP_TOP() do {} while (0)
+#endif
 
 template <int CTRL>
 __device__ __forceinline__ float ap_dpp(float v) {
@@ -64,8 +89,18 @@ __device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are d
   asm volatile("" ::: "memory");
 }
 
-template <int DT, int R, int QB, bool AM>
-__global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
+// (timing experiments of the diagnostic build: -DAP_ABLATE_DMA=1 drops the loop's LDS-DMA instructions, -DAP_ABLATE_MFMA=1
+//  its MFMAs; results are then wrong, only the time is of interest)
+#ifndef AP_ABLATE_DMA
+#define AP_ABLATE_DMA 0
+#endif
+#ifndef AP_ABLATE_MFMA
+#define AP_ABLATE_MFMA 0
+#endif
+
+template <int DT, int R, int QB, bool AM, int WV>
+__global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs a) {
+  static_assert(WV == 8 || WV == 4, "8 waves = 4 (rows) x 2 (queries), or 4 waves = 2 x 2 with twice the row blocks each");
   static_assert(DT == MAXSIM_F16 || DT == MAXSIM_BF16, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NQ = 2 * QB;                     // queries of a tile
@@ -74,8 +109,10 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   constexpr int STAGE = ROWS * 64;               // bytes: 32 dims x 2 B per row
   constexpr int NST = 4;                         // ring stages: slice g being read, g + 1 ready (its first fragments are
                                                  // prefetched across the barrier), g + 2 and g + 3 in flight
-  constexpr int NI = ROWS / 16;                  // LDS-DMA instructions per slice (16 rows each): wave w issues w, w + 8, ...
-  constexpr int NMAX = (NI + 7) / 8;
+  constexpr int NI = ROWS / 16;                  // LDS-DMA instructions per slice (16 rows each): wave w issues w, w + WV, ...
+  constexpr int WM = WV / 2;                     // row-waves
+  constexpr int RW = 4 * R / WM;                 // 32-row blocks of a wave
+  constexpr int NMAX = (NI + WV - 1) / WV;
   constexpr int NAI = TM / 16;                   // instructions < NAI move doc rows, the others query rows
   float* const ex_v = (float*)(lds + NST * STAGE);      // [NQ][4 wm][32]: per-wave (max) ...
   int* const ex_i = (int*)(ex_v + NQ * 4 * 32);         // ... and (first index)
@@ -87,12 +124,19 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   const lds_ptr_t dm_dst = (lds_ptr_t)LPTR(dm_lds), qm_dst = (lds_ptr_t)LPTR(qm_lds);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6), wm = wave & 3, wn = wave >> 2;
+  const int wave = uni(tid >> 6), wm = wave & (WM - 1), wn = wave / WM;
   const int r = lane & 31, hh = lane >> 5;
   const int nslices = a.h >> 5;
   const int64_t rowb = (int64_t)a.h * 2;
   const int nqb = (a.nq + NQ - 1) / NQ;
-  const int my_ndma = (NI - wave + 7) / 8;  // this wave's LDS-DMA instructions per slice (NMAX or NMAX - 1)
+  const int my_ndma = (NI - wave + WV - 1) / WV;
+#ifdef MAXSIM_DIAG
+  uint64_t* const st_lds = (uint64_t*)(qm_lds + NQ * 32);
+  const int stamp_w = (int)blockIdx.x != a.stamp_wg ? -1 : wave == 0 ? 0 : wave == WV - 1 ? 1 : -1;
+  if ((int)blockIdx.x == a.stamp_wg) {
+    for (int i = tid; i < 2 * 24 * 9; i += WV * 64) st_lds[i] = 0;
+  }
+#endif  // this wave's LDS-DMA instructions per slice (NMAX or NMAX - 1)
 
   // ---- this workgroup's tiles: XCD x = id % 8 owns docs x, x + 8, ...; its workgroups walk (doc, query block) in order
   const int x = blockIdx.x & 7, l = blockIdx.x >> 3, nl = max(1, (int)gridDim.x >> 3);
@@ -112,10 +156,10 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   uint32_t off0[NMAX];  // query rows: the same for slot 0 (used for slots past nq in the last, partial query block)
 #pragma unroll
   for (int j = 0; j < NMAX; ++j) {
-    const int ins = wave + 8 * j;
+    const int ins = wave + WV * j;
     const int lr = 16 * ins + (lane >> 2);
     const uint32_t chunk = (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) * 16);
-    if (j < R) {
+    if (j < NAI / WV) {
       off[j] = (uint32_t)(min(lr, a.Ld - 1) * (int)rowb) + chunk;  // rows past Ld re-read the last row (never candidates)
       off0[j] = 0;
     } else {
@@ -143,16 +187,16 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     const char* const qbase = is_qbase + is_s * 64;
 #pragma unroll
     for (int j = 0; j < NMAX; ++j) {
-      const int ins = wave + 8 * j;                                           // wave-uniform
+      const int ins = wave + WV * j;                                           // wave-uniform
       if (ins >= NI) break;
       const char* g_ptr;
-      if (j < R) {                                                            // (doc rows = the first 8 R instructions)
+      if (j < NAI / WV) {                                                     // (doc rows = the first 8 R instructions)
         g_ptr = dbase + off[j];
       } else {
         const int lr = 16 * ins + (lane >> 2);
         g_ptr = qbase + (((lr - TM) >> 5) < is_nvalid ? off[j] : off0[j]);   // slots past nq re-read slot 0
       }
-      __builtin_amdgcn_global_load_lds(GPTR(g_ptr), LPTR(dst + j * 8192), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds(GPTR(g_ptr), LPTR(dst + j * (WV * 1024)), 16, 0, 0);
     }
     if (++is_s == nslices) { is_s = 0; ++is_ti; }
   };
@@ -160,25 +204,25 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   // ---- compute side: fragment addresses inside a stage
   //      A fragment of row block b, k-step ks: row 32 b + r, chunk 2 ks + hh at position chunk ^ ((row >> 2) & 3)
   const int swz = (r >> 2) & 3;
-  f32x16 acc[R][QB];
+  f32x16 acc[RW][QB];
 #pragma unroll
-  for (int b = 0; b < R; ++b)
+  for (int b = 0; b < RW; ++b)
 #pragma unroll
     for (int q = 0; q < QB; ++q) acc[b][q] = (f32x16)(0.0f);
 
   // fragment sets, double-buffered: while the MFMAs of one k-step run, the next k-step's fragments are on their way from
   // LDS (a workgroup's waves hit the barrier together; without this overlap the LDS read phase -- 96 KB per slice and CU,
   // 768 cycles at 128 B/clk -- and the MFMA phase -- 1152 cycles per SIMD -- serialise: measured 35 % MFMA busy)
-  u32x4 fa[2][R], fb[2][QB];
+  u32x4 fa[2][RW], fb[2][QB];
   auto load_frags = [&](int set, int g, int ks) __attribute__((always_inline)) {
     const char* const st = lds + (g % NST) * STAGE;
     const int pos = ((2 * ks + hh) ^ swz) * 16;
     // ds_read_b128 by hand: the compiler would wait for a set with s_waitcnt lgkmcnt(0) -- i.e. also for the set it has
     // just issued -- because it cannot count LDS returns across the loop back edge; wait_frags counts them instead
-    const uint32_t aa = (uint32_t)(size_t)(st + ((wm * R) * 32 + r) * 64 + pos - lds);
+    const uint32_t aa = (uint32_t)(size_t)(st + ((wm * RW) * 32 + r) * 64 + pos - lds);
     const uint32_t ab = (uint32_t)(size_t)(st + (TM + (wn * QB) * 32 + r) * 64 + pos - lds);
 #pragma unroll
-    for (int b = 0; b < R; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][b]) : "v"(aa), "n"(b * 2048));
+    for (int b = 0; b < RW; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][b]) : "v"(aa), "n"(b * 2048));
 #pragma unroll
     for (int q = 0; q < QB; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][q]) : "v"(ab), "n"(q * 2048));
   };
@@ -186,7 +230,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   auto wait_frags = [&](int set) __attribute__((always_inline)) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
-    for (int b = 0; b < R; ++b) asm volatile("" : "+v"(fa[set][b]));  // (the MFMAs below depend on this point)
+    for (int b = 0; b < RW; ++b) asm volatile("" : "+v"(fa[set][b]));  // (the MFMAs below depend on this point)
 #pragma unroll
     for (int q = 0; q < QB; ++q) asm volatile("" : "+v"(fb[set][q]));
   };
@@ -197,21 +241,21 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   const bool masked = a.mask_dtype != MAXSIM_MASK_NONE;
   // rows past Ld are tile padding: their mask word is NaN for the whole kernel, so their products are NaN and never win a
   // `>` (no bound test per element in the epilogue); without masks every real row / token weighs 1
-  for (int i = tid; i < TM + NQ * 32; i += 512) {
+  for (int i = tid; i < TM + NQ * 32; i += WV * 64) {
     const bool pad = i >= a.Ld && i < TM;
     if (pad || !masked) dm_lds[i] = pad ? __builtin_nanf("") : 1.0f;
   }
-  auto issue_masks = [&](int ti) __attribute__((always_inline)) {  // waves 6 and 7, after their part of a tile's first slice
+  auto issue_masks = [&](int ti) __attribute__((always_inline)) {  // the last two waves, after their part of a tile's first slice
     const int u = l + ti * nl;
     const int d = tile_doc(u), q0 = tile_q0(u);
-    if (wave == 6) {
+    if (wave == WV - 2) {
 #pragma unroll
       for (int j = 0; j < TM / 64; ++j) {
         const int row = j * 64 + lane;
         if (row < a.Ld)  // (lanes past Ld stay out: their words keep the NaN)
           __builtin_amdgcn_global_load_lds(GPTR((const float*)a.d_mask + (int64_t)d * a.Ld + row), (__attribute__((address_space(3))) void*)(dm_dst + j * 256), 4, 0, 0);
       }
-    } else if (wave == 7) {
+    } else if (wave == WV - 1) {
 #pragma unroll
       for (int j = 0; j < NQ / 2; ++j) {
         const int slot = 2 * j + (lane >> 5);
@@ -225,7 +269,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   if (total > 2) issue(2);
   if (total > 0 && masked) issue_masks(0);
   if (total > 0) {  // slice 0 for everybody, its first fragments on their way
-    if (masked && wave >= 6) wait_vmcnt<0>();  // (their mask rows sit behind the slices in the queue: once, at start)
+    if (masked && wave >= WV - 2) wait_vmcnt<0>();  // (their mask rows sit behind the slices in the queue: once, at start)
     else if (total > 2) { if (my_ndma == NMAX) wait_vmcnt<2 * NMAX>(); else wait_vmcnt<2 * NMAX - 2>(); }
     else if (total > 1) { if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>(); }
     else wait_vmcnt<0>();
@@ -270,26 +314,36 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     // fragment addresses: (g, k-step 1) for set 1, (g + 1, k-step 0) for set 0 (past the last slice: a stale stage, dropped)
     const uint32_t st1 = (uint32_t)((g % NST) * STAGE), st0 = (uint32_t)(((g + 1) % NST) * STAGE);
     const uint32_t pos1 = (uint32_t)(((2 + hh) ^ swz) * 16), pos0 = (uint32_t)((hh ^ swz) * 16);
-    t.a1 = st1 + ((wm * R) * 32 + r) * 64 + pos1;
+    t.a1 = st1 + ((wm * RW) * 32 + r) * 64 + pos1;
     t.b1 = st1 + (TM + (wn * QB) * 32 + r) * 64 + pos1;
-    t.a0 = st0 + ((wm * R) * 32 + r) * 64 + pos0;
+    t.a0 = st0 + ((wm * RW) * 32 + r) * 64 + pos0;
     t.b0 = st0 + (TM + (wn * QB) * 32 + r) * 64 + pos0;
     return t;
   };
   Step cur = prep(0);
+#ifdef MAXSIM_DIAG
+  uint64_t tS[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (int g = 0; g < total; ++g) {
     const int s = cur.s, ti = cur.ti;
     // slice g + 1 has landed: this wave's part (counted: the instructions of slice g + 2 may still be in flight.  Loads retire
     // in order, so "at most my_ndma outstanding" implies slice g + 1 is in whatever the epilogue's younger stores and the
     // mask rows are doing: at worst the wait runs a few instructions into slice g + 2), then everybody's.  The barrier also
     // says: every wave is done reading slice g - 1, whose stage slice g + 3 overwrites.
+    AP_STAMP_TOP();
     if (cur.vm_all) wait_vmcnt<0>(); else if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>();
+    AP_STAMP(1);
     wg_barrier();
+    AP_STAMP(2);
     // One slice = two k-steps of R QB MFMAs, with the R + QB fragment reads of the next k-step and the LDS-DMA
     // instructions of slice g + 3 between them.
-    constexpr int NM = R * QB, NF = R + QB;
+    constexpr int NM = RW * QB, NF = RW + QB;
     constexpr int SLOTS = NM > NF ? NM - NF : 1, PER = (NMAX + SLOTS - 1) / SLOTS;  // DMA instructions per late MFMA
-    const bool do_issue = cur.do_issue;
+    // The two waves of a SIMD (w and w + WV / 2) issue their LDS-DMA instructions in DIFFERENT k-steps: an LDS-DMA
+    // instruction holds the issuing wave for 100-180 cycles (stamped: k-step 0 with this wave's 4-5 instructions took
+    // 780-1080 cycles, k-step 1 without them 200-260), and with both partners stalled at the same point of the slice
+    // nobody fed the matrix pipe meanwhile.
+    const bool do_issue0 = cur.do_issue && wave < WV / 2, do_issue1 = cur.do_issue && wave >= WV / 2;
     const bool first = cur.first;
     char* const dma_dst = cur.dma_dst;
     const char* const dma_db = cur.dma_db;
@@ -298,16 +352,18 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
 // "doc or query rows" depends on j alone; only the last j can fall off the end of the image (runtime test on the wave)
 #define AP_DMA(j)                                                                                                     \
   do {                                                                                                                \
-    if ((j) < NI / 8 || wave < NI - 8 * (j)) {                                                                        \
+    if (AP_ABLATE_DMA) break;                                                                                         \
+    if ((j) < NI / WV || wave < NI - WV * (j)) {                                                                      \
       const char* gp_;                                                                                                \
-      if ((j) < R) gp_ = dma_db + off[j];                                                                             \
-      else gp_ = dma_qb + ((((16 * (wave + 8 * (j)) + (lane >> 2)) - TM) >> 5) < is_nvalid_cur ? off[j] : off0[j]);  \
-      __builtin_amdgcn_global_load_lds(GPTR(gp_), LPTR(dma_dst + (j) * 8192), 16, 0, 0);                            \
+      if ((j) < NAI / WV) gp_ = dma_db + off[j];                                                                      \
+      else gp_ = dma_qb + ((((16 * (wave + WV * (j)) + (lane >> 2)) - TM) >> 5) < is_nvalid_cur ? off[j] : off0[j]);  \
+      __builtin_amdgcn_global_load_lds(GPTR(gp_), LPTR(dma_dst + (j) * (WV * 1024)), 16, 0, 0);                     \
     }                                                                                                                 \
   } while (0)
 #define AP_MFMA(set, i, c0)                                                                                           \
   do {                                                                                                                \
-    const int q_ = (i) / R, b_ = (i) % R;                                                                             \
+    if (AP_ABLATE_MFMA) break;                                                                                        \
+    const int q_ = (i) / RW, b_ = (i) % RW;                                                                            \
     const f32x16 c_ = (c0) ? (f32x16)(0.0f) : acc[b_][q_];                                                            \
     if constexpr (DT == MAXSIM_F16)                                                                                   \
       acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][b_]), __builtin_bit_cast(f16x8, fb[set][q_]), c_, 0, 0, 0); \
@@ -318,16 +374,17 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     const uint32_t a1 = cur.a1, b1 = cur.b1, a0 = cur.a0, b0 = cur.b0;
     wait_frags(0);  // set 0 (requested during the previous k-step) is in: no younger LDS read is outstanding here
     if (cur.do_masks) issue_masks(ti);
+    AP_STAMP(3);
     // ---- k-step 0: MFMAs on set 0, between them the reads of set 1, then the LDS-DMA instructions of slice g + 3
     //      (two copies, so that "a tile's first k-step starts from C = 0" is ONE branch per slice, not one per MFMA)
 #define AP_KSTEP0(C0)                                                                                                 \
   _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                                    \
     AP_MFMA(0, i, C0);                                                                                                \
-    if (i < R) {                                                                                                      \
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < R ? i : 0]) : "v"(a1), "n"(i * 2048));           \
+    if (i < RW) {                                                                                                     \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < RW ? i : 0]) : "v"(a1), "n"(i * 2048));           \
     } else if (i < NF) {                                                                                              \
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= R && i < NF ? i - R : 0]) : "v"(b1), "n"((i - R) * 2048)); \
-    } else if (do_issue) {                                                                                            \
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= RW && i < NF ? i - RW : 0]) : "v"(b1), "n"((i - RW) * 2048)); \
+    } else if (do_issue0) {                                                                                           \
       _Pragma("unroll") for (int t = 0; t < PER; ++t) {                                                               \
         const int j = (i - NF) * PER + t;                                                                             \
         if (j < NMAX) AP_DMA(j < NMAX ? j : 0);                                                                       \
@@ -339,30 +396,44 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     // (what did not fit between the MFMAs: R QB < R + QB happens for R = 1)
 #pragma unroll
     for (int i = NM; i < NF; ++i) {
-      if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < R ? i : 0]) : "v"(a1), "n"(i * 2048));
-      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= R && i < NF ? i - R : 0]) : "v"(b1), "n"((i - R) * 2048));
+      if (i < RW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < RW ? i : 0]) : "v"(a1), "n"(i * 2048));
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= RW && i < NF ? i - RW : 0]) : "v"(b1), "n"((i - RW) * 2048));
     }
-    if (NM <= NF && do_issue) {
+    if (NM <= NF && do_issue0) {
 #pragma unroll
       for (int j = 0; j < NMAX; ++j) AP_DMA(j);
     }
+    AP_STAMP(4);
     wait_frags(1);
+    AP_STAMP(5);
     // ---- k-step 1: MFMAs on set 1, between them the reads of the next slice's set 0
     Step nxt = cur;
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       AP_MFMA(1, i, false);
-      if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < R ? i : 0]) : "v"(a0), "n"(i * 2048));
-      else if (i < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= R && i < NF ? i - R : 0]) : "v"(b0), "n"((i - R) * 2048));
+      if (i < RW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < RW ? i : 0]) : "v"(a0), "n"(i * 2048));
+      else if (i < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= RW && i < NF ? i - RW : 0]) : "v"(b0), "n"((i - RW) * 2048));
+      else if (do_issue1) {
+#pragma unroll
+        for (int t = 0; t < PER; ++t) {
+          const int j = (i - NF) * PER + t;
+          if (j < NMAX) AP_DMA(j < NMAX ? j : 0);
+        }
+      }
       if (i == (NM > 2 ? 2 : NM - 1)) nxt = prep(g + 1);  // the next iteration's bookkeeping, under this k-step's MFMAs
     }
 #pragma unroll
     for (int i = NM; i < NF; ++i) {
-      if (i < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < R ? i : 0]) : "v"(a0), "n"(i * 2048));
-      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= R && i < NF ? i - R : 0]) : "v"(b0), "n"((i - R) * 2048));
+      if (i < RW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < RW ? i : 0]) : "v"(a0), "n"(i * 2048));
+      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= RW && i < NF ? i - RW : 0]) : "v"(b0), "n"((i - RW) * 2048));
+    }
+    if (NM <= NF && do_issue1) {
+#pragma unroll
+      for (int j = 0; j < NMAX; ++j) AP_DMA(j);
     }
 #undef AP_DMA
 #undef AP_MFMA
+    AP_STAMP(6);
     if (s + 1 < nslices) {
       cur = nxt;
       continue;
@@ -376,34 +447,42 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       const int qq = q0 + wn * QB + q;
       // tokens past Lq and query slots past nq: weight 0 (similarity 0, nothing written)
       const float qm = (qq < a.nq && r < a.Lq) ? qm_lds[(wn * QB + q) * 32 + r] : 0.0f;
+      // q_mask >= 0 (the reference's masks are 0/1: tokenizers.py:36,57) commutes with the max: max_n(qm x_n) = qm max_n(x_n),
+      // one multiplication per token instead of one per similarity.  A negative weight anywhere in the wave (never built
+      // by the reference, allowed by its interface) takes the multiplication back into the mask words of every block.
+      const bool premul = __builtin_amdgcn_ballot_w64(qm < 0.0f) != 0;
       float best = NEG_INF;
-      int bidx = 0;
-#pragma unroll
-      for (int b = 0; b < R; ++b) {
-        int rowbase = (wm * R + b) * 32 + 4 * hh;
-        asm volatile("" : "+v"(rowbase));  // opaque: otherwise the row numbers / mask words are shared by the QB unrolled
-                                           // query iterations and stay live across all of them (registers)
-        // d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait (a read + wait per pair of
-        // rows made the epilogue cost as much as the whole K loop: 14 us per tile)
-        f32x4 d4[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm_lds + rowbase + 8 * k);  // NaN past Ld (tile padding)
-#pragma unroll
-        for (int v = 0; v < 16; v += 2) {  // rows in increasing order, two at a time (v_pk_mul_f32)
-          const int row = rowbase + (v & 3) + 8 * (v >> 2);
-          f32x2 w = {d4[v >> 2][v & 3], d4[v >> 2][(v & 3) + 1]};
-          w *= qm;
-          f32x2 sim = {acc[b][q][v], acc[b][q][v + 1]};
-          sim *= w;                                            // (Q q_mask) . (D d_mask), BaseModel.py:41-43
-#pragma unroll
-          for (int e = 0; e < 2; ++e) {
-            const bool better = sim[e] > best;                 // strict >: the first maximal token wins (torch.max);
-            best = better ? sim[e] : best;                     // a NaN (row past Ld) never does
-            if (AM) bidx = better ? row + e : bidx;
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);  // (one block's mask words at a time)
-      }
+      int bidx = 0;  // position b * 16 + v of the winner among this lane's values (compile-time numbers: no arithmetic per
+                     // value; turned into a row number once, below)
+      // (two copies of the scan, chosen per wave: a conditional multiplication inside one copy cost 12 registers -> spills)
+#define AP_SCAN(PREMUL)                                                                                               \
+  _Pragma("unroll") for (int b = 0; b < RW; ++b) {                                                                    \
+    int rowbase = (wm * RW + b) * 32 + 4 * hh;                                                                        \
+    /* opaque: otherwise the mask words are shared by the QB unrolled query iterations and stay live across them */   \
+    asm volatile("" : "+v"(rowbase));                                                                                 \
+    /* d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait (a read + wait per pair of */ \
+    /* rows made the epilogue cost as much as the whole K loop: 14 us per tile); NaN past Ld (tile padding) */        \
+    f32x4 d4[4];                                                                                                      \
+    _Pragma("unroll") for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm_lds + rowbase + 8 * k);                  \
+    _Pragma("unroll") for (int v = 0; v < 16; v += 2) { /* rows in increasing order, two at a time (v_pk_mul_f32) */  \
+      f32x2 w = {d4[v >> 2][v & 3], d4[v >> 2][(v & 3) + 1]};                                                         \
+      if (PREMUL) w *= qm;                                                                                            \
+      f32x2 sim = {acc[b][q][v], acc[b][q][v + 1]};                                                                   \
+      sim *= w; /* . d_mask (. q_mask: in w, or after the scan) */                                                    \
+      _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                 \
+        const bool better = sim[e] > best; /* strict >: the first maximal token wins (torch.max); a NaN never does */ \
+        best = better ? sim[e] : best;                                                                                \
+        if (AM) bidx = better ? b * 16 + v + e : bidx;                                                                \
+      }                                                                                                               \
+    }                                                                                                                 \
+    __builtin_amdgcn_sched_barrier(0); /* (one block's mask words at a time) */                                       \
+  }
+      if (premul) { AP_SCAN(true) } else { AP_SCAN(false) }
+#undef AP_SCAN
+      // (Q q_mask) . (D d_mask), BaseModel.py:41-43.  q_mask = 0 makes every similarity of the token 0: the first row wins
+      const bool qzero = !premul && qm == 0.0f;
+      if (!premul) best = qzero ? 0.0f : best * qm;
+      if (AM) bidx = qzero ? (wm == 0 && hh == 0 ? 0 : 0x7fffffff) : (wm * RW + (bidx >> 4)) * 32 + 4 * hh + (bidx & 3) + 8 * ((bidx & 15) >> 2);
       // the two lane halves hold interleaved rows of the same query token
       const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
       const float va = __uint_as_float(sv[0]), vb = __uint_as_float(sv[1]);
@@ -419,22 +498,23 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
         v2 = fmaxf(va, vb);
       }
       if (lane < 32) {
-        ex_v[((wn * QB + q) * 4 + wm) * 32 + lane] = v2;
-        if (AM) ex_i[((wn * QB + q) * 4 + wm) * 32 + lane] = i2;
+        ex_v[((wn * QB + q) * WM + wm) * 32 + lane] = v2;
+        if (AM) ex_i[((wn * QB + q) * WM + wm) * 32 + lane] = i2;
       }
     }
     lds_barrier();
-    // the row-waves' results meet: wave w finishes query slot w of the tile (NQ <= 8 slots)
-    if (wave < NQ) {
-      const int qq = q0 + wave;
+    // the row-waves' results meet: wave w finishes query slots w, w + WV, ... of the tile
+#pragma unroll
+    for (int qs = wave; qs < NQ; qs += WV) {
+      const int qq = q0 + qs;
       float best = NEG_INF;
       int bidx = 0;
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {  // increasing row ranges: strict > keeps the first maximal token
-        const float v = ex_v[(wave * 4 + w) * 32 + r];
+      for (int w = 0; w < WM; ++w) {  // increasing row ranges: strict > keeps the first maximal token
+        const float v = ex_v[(qs * WM + w) * 32 + r];
         const bool better = v > best;
         best = better ? v : best;
-        if (AM) bidx = better ? ex_i[(wave * 4 + w) * 32 + r] : bidx;
+        if (AM) bidx = better ? ex_i[(qs * WM + w) * 32 + r] : bidx;
       }
       if (qq < a.nq) {
         if (AM && lane < a.Lq) a.argmax[((int64_t)qq * a.nd + d) * a.Lq + lane] = bidx;
@@ -449,8 +529,15 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       }
     }
     // (the exchange area is rewritten only after the next tile's slices, i.e. after many more barriers)
+    AP_STAMP(7);
     cur = nxt;
   }
+#ifdef MAXSIM_DIAG
+  if ((int)blockIdx.x == a.stamp_wg) {
+    __syncthreads();
+    for (int i = tid; i < 2 * 24 * 9; i += WV * 64) g_ap_stamps[i] = st_lds[i];
+  }
+#endif
 }
 
 }  // namespace maxsim

@@ -18,21 +18,31 @@ int cu_count() {  // workgroups are persistent, one per CU; the XCD-aware tile w
   return cus[dev];
 }
 
-template <int DT, int R, int QB, bool AM>
+template <int DT, int R, int QB, bool AM, int WV>
 int launch_r(const AllPairsArgs& a, hipStream_t st) {
+#ifdef MAXSIM_DIAG
+  constexpr int ldsb = 4 * (128 * R + 64 * QB) * 64 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4 + 2 * 24 * 9 * 8;
+#else
   constexpr int ldsb = 4 * (128 * R + 64 * QB) * 64 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4;
-  auto kern = k_maxsim_allpairs<DT, R, QB, AM>;
+#endif
+  auto kern = k_maxsim_allpairs<DT, R, QB, AM, WV>;
   int rc = allow_lds(kern, ldsb);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)cu_count()), dim3(512), ldsb, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)cu_count()), dim3(WV * 64), ldsb, st, a);
   return check_launch();
 }
 
 template <int DT, bool AM>
 int launch_dt(const AllPairsArgs& a, hipStream_t st) {
-  if (a.Ld <= 128) return launch_r<DT, 1, 4, AM>(a, st);
-  if (a.Ld <= 256) return launch_r<DT, 2, 4, AM>(a, st);
-  return launch_r<DT, 3, 3, AM>(a, st);
+  const int wv = MAXSIM_KNOB("MAXSIM_ALLPAIRS_WAVES", 8);
+  if (wv == 4) {
+    if (a.Ld <= 128) return launch_r<DT, 1, 4, AM, 4>(a, st);
+    if (a.Ld <= 256) return launch_r<DT, 2, 3, AM, 4>(a, st);
+    return launch_r<DT, 3, 2, AM, 4>(a, st);
+  }
+  if (a.Ld <= 128) return launch_r<DT, 1, 4, AM, 8>(a, st);
+  if (a.Ld <= 256) return launch_r<DT, 2, 4, AM, 8>(a, st);
+  return launch_r<DT, 3, 3, AM, 8>(a, st);
 }
 
 }  // namespace
@@ -52,9 +62,19 @@ int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st) {
   AllPairsArgs a{};
   a.Q = p.Q; a.D = p.index; a.q_mask = p.q_mask; a.d_mask = p.d_mask;
   a.scores = p.scores; a.argmax = p.argmax;
+#ifdef MAXSIM_DIAG
+  a.stamp_g0 = MAXSIM_KNOB("MAXSIM_AP_STAMP_G0", 48);
+  a.stamp_wg = MAXSIM_KNOB("MAXSIM_AP_STAMP_WG", -1);
+#endif
   a.mask_dtype = p.mask_dtype; a.nq = p.nq; a.nd = p.ncand; a.Lq = p.Lq; a.Ld = p.Ld; a.h = p.h;
   if (dt == MAXSIM_F16) return argmax ? launch_dt<MAXSIM_F16, true>(a, st) : launch_dt<MAXSIM_F16, false>(a, st);
   return argmax ? launch_dt<MAXSIM_BF16, true>(a, st) : launch_dt<MAXSIM_BF16, false>(a, st);
 }
 
 }  // namespace maxsim
+
+#ifdef MAXSIM_DIAG
+extern "C" int maxsim_diag_allpairs_stamps(uint64_t* out) {  // host copy of the last stamped launch (diagnostic build)
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(maxsim::g_ap_stamps), sizeof(maxsim::g_ap_stamps)) == hipSuccess ? 0 : -1;
+}
+#endif

@@ -437,3 +437,43 @@ def test_allpairs_kernel_matches_streaming_kernel_and_oracle(ca, cfg):
         assert bool((got >= 0).all()) and bool((got < Ld).all()), name
         assert bool((got[clear] == ref_idx[clear]).all()), name
     assert float(clear.float().mean()) > 0.5
+    # a query token of weight 0 has every similarity 0: torch.max returns the first token
+    dropped = (qm == 0)[:, None, :].expand(nq, nd, Lq)
+    for name in ("gemm", "stream"):
+        assert bool((res[name][1][dropped] == 0).all()), name
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("Ld", [100, 200, 300])
+def test_allpairs_kernel_general_float_masks(ca, Ld):
+    """Masks the reference never builds but its interface allows: fractional, negative and zero float32 weights on both
+    sides (BaseModel.py:41-43 multiplies whatever it is given).  The GEMM-blocked kernel applies a non-negative q_mask
+    after the max and takes the multiplication back into every similarity when a weight is negative; both paths against
+    float64 on the rounded inputs, arg-max wherever the top two are clearly apart."""
+    from colbert_amd.scoring import _DT, _MDT
+    L = ca._lib.lib
+    gen = torch.Generator().manual_seed(77)
+    nq, nd, Lq, h, dt = 24, 64, 32, 128, torch.bfloat16     # 64 x 3 tiles: enough for the GEMM-blocked kernel
+    Q = nrm(gen, nq, Lq, h).to(dt)
+    D = nrm(gen, nd, Ld, h).to(dt)
+    qm = torch.rand(nq, Lq, generator=gen) * 1.5
+    qm[torch.rand(nq, Lq, generator=gen) < 0.2] = 0.0
+    qm[::3] *= torch.where(torch.rand(nq // 3, Lq, generator=gen) < 0.3, -1.0, 1.0)     # every third query: some negative
+    dm = torch.rand(nd, Ld, generator=gen) * 2 - 0.5
+    dm[torch.rand(nd, Ld, generator=gen) < 0.2] = 0.0
+    out = torch.empty(nq, nd, device="cuda")
+    arg = torch.full((nq, nd, Lq), -7, dtype=torch.int32, device="cuda")
+    Qd, Dd, qmd, dmd = Q.cuda(), D.cuda(), qm.cuda(), dm.cuda()
+    rc = L.maxsim_score_dense_fwd(Qd.data_ptr(), Dd.data_ptr(), qmd.data_ptr(), dmd.data_ptr(), nq, nd, Lq, Ld, h,
+                                  _DT[dt], _MDT[torch.float32], out.data_ptr(), arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    sim = torch.einsum("qmh,dnh->qdmn", Q.double(), D.double()) * qm.double()[:, None, :, None] * dm.double()[None, :, None, :]
+    exp = sim.max(-1).values.sum(-1)
+    torch.testing.assert_close(out.cpu().double(), exp, rtol=0, atol=2e-3)
+    top2 = sim.topk(2, dim=-1).values
+    clear = top2[..., 0] - top2[..., 1] > 1e-4
+    got = arg.cpu()
+    assert bool((got >= 0).all()) and bool((got < Ld).all())
+    assert bool((got[clear] == sim.argmax(-1).to(torch.int32)[clear]).all())
+    assert float(clear.float().mean()) > 0.5
