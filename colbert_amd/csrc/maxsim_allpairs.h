@@ -98,9 +98,10 @@ __device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are d
 #define AP_ABLATE_MFMA 0
 #endif
 
-template <int DT, int R, int QB, bool AM, int WV>
-__global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs a) {
-  static_assert(WV == 8 || WV == 4, "8 waves = 4 (rows) x 2 (queries), or 4 waves = 2 x 2 with twice the row blocks each");
+template <int DT, int R, int QB, bool AM>
+__global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
+  constexpr int WV = 8;  // waves: 4 (doc rows) x 2 (queries).  (Four waves of twice the rows, one per SIMD with 512 registers,
+                         // were slower: the accumulators must then fit the 256 AGPRs, i.e. 6 x 2 blocks at best.)
   static_assert(DT == MAXSIM_F16 || DT == MAXSIM_BF16, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NQ = 2 * QB;                     // queries of a tile
@@ -109,11 +110,14 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
   constexpr int STAGE = ROWS * 64;               // bytes: 32 dims x 2 B per row
   constexpr int NST = 4;                         // ring stages: slice g being read, g + 1 ready (its first fragments are
                                                  // prefetched across the barrier), g + 2 and g + 3 in flight
-  constexpr int NI = ROWS / 16;                  // LDS-DMA instructions per slice (16 rows each): wave w issues w, w + WV, ...
+  constexpr int NI = ROWS / 16;                  // LDS-DMA instructions per slice (16 rows each)
   constexpr int WM = WV / 2;                     // row-waves
   constexpr int RW = 4 * R / WM;                 // 32-row blocks of a wave
-  constexpr int NMAX = (NI + WV - 1) / WV;
   constexpr int NAI = TM / 16;                   // instructions < NAI move doc rows, the others query rows
+  constexpr int HW = WV / 2;                     // waves 0 .. HW - 1 fetch the doc rows, HW .. WV - 1 the query rows: a wave
+  constexpr int NDA = NAI / HW;                  // and its SIMD partner (w, w + HW) sit in different halves
+  constexpr int NDB = (NI - NAI) / HW;           // LDS-DMA instructions per slice of a doc-row wave (2 R) / query-row wave (QB)
+  constexpr int NOFF = NDA > 2 * NDB ? NDA : 2 * NDB;
   float* const ex_v = (float*)(lds + NST * STAGE);      // [NQ][4 wm][32]: per-wave (max) ...
   int* const ex_i = (int*)(ex_v + NQ * 4 * 32);         // ... and (first index)
   float* const dm_lds = (float*)(ex_i + NQ * 4 * 32);   // [TM]: d_mask row of the tile's doc
@@ -129,14 +133,15 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
   const int nslices = a.h >> 5;
   const int64_t rowb = (int64_t)a.h * 2;
   const int nqb = (a.nq + NQ - 1) / NQ;
-  const int my_ndma = (NI - wave + WV - 1) / WV;
+  const bool fetch_docs = wave < HW;
+  const int hw = wave & (HW - 1);
 #ifdef MAXSIM_DIAG
   uint64_t* const st_lds = (uint64_t*)(qm_lds + NQ * 32);
   const int stamp_w = (int)blockIdx.x != a.stamp_wg ? -1 : wave == 0 ? 0 : wave == WV - 1 ? 1 : -1;
   if ((int)blockIdx.x == a.stamp_wg) {
     for (int i = tid; i < 2 * 24 * 9; i += WV * 64) st_lds[i] = 0;
   }
-#endif  // this wave's LDS-DMA instructions per slice (NMAX or NMAX - 1)
+#endif
 
   // ---- this workgroup's tiles: XCD x = id % 8 owns docs x, x + 8, ...; its workgroups walk (doc, query block) in order
   const int x = blockIdx.x & 7, l = blockIdx.x >> 3, nl = max(1, (int)gridDim.x >> 3);
@@ -152,21 +157,19 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
   //      conflict-free).  Everything lane-dependent is a 32-bit offset computed ONCE (the address of an instruction is a
   //      wave-uniform 64-bit base + that offset: no vector arithmetic per slice -- with two waves per SIMD in the same
   //      phase, every VALU cycle spent here is a cycle the matrix pipe idles).
-  uint32_t off[NMAX];   // doc rows: min(row, Ld - 1) * rowb + chunk; query rows: (slot * Lq + min(token, Lq - 1)) * rowb + chunk
-  uint32_t off0[NMAX];  // query rows: the same for slot 0 (used for slots past nq in the last, partial query block)
+  //      Doc-row wave hw moves image rows 16 (hw + HW j) .. + 15 (j < NDA), query-row wave hw the rows TM + 16 (hw + HW j) ..
+  //      (j < NDB).  off[j]: doc rows min(row, Ld - 1) * rowb + chunk; query rows (slot * Lq + min(token, Lq - 1)) * rowb +
+  //      chunk and, at NDB + j, the same for slot 0 (used for slots past nq in the last, partial query block).
+  uint32_t off[NOFF];
 #pragma unroll
-  for (int j = 0; j < NMAX; ++j) {
-    const int ins = wave + WV * j;
-    const int lr = 16 * ins + (lane >> 2);
-    const uint32_t chunk = (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) * 16);
-    if (j < NAI / WV) {
-      off[j] = (uint32_t)(min(lr, a.Ld - 1) * (int)rowb) + chunk;  // rows past Ld re-read the last row (never candidates)
-      off0[j] = 0;
-    } else {
-      const int slot = (lr - TM) >> 5, t = min((lr - TM) & 31, a.Lq - 1);  // tokens past Lq re-read the last token (weight 0)
-      off[j] = (uint32_t)((slot * a.Lq + t) * (int)rowb) + chunk;
-      off0[j] = (uint32_t)(t * (int)rowb) + chunk;
-    }
+  for (int j = 0; j < NOFF; ++j) {
+    const int jj = fetch_docs ? j : j % NDB;
+    const int lr = 16 * (hw + HW * jj) + (lane >> 2);  // row within the doc part / the query part of the image
+    const uint32_t chunk = (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) * 16);  // (TM % 16 == 0: the same swizzle either way)
+    const int slot = lr >> 5, t = min(lr & 31, a.Lq - 1);  // tokens past Lq re-read the last token (weight 0)
+    const uint32_t od = (uint32_t)(min(lr, a.Ld - 1) * (int)rowb);  // rows past Ld re-read the last row (never candidates)
+    const uint32_t oq = (uint32_t)(((j < NDB ? slot * a.Lq : 0) + t) * (int)rowb);
+    off[j] = (fetch_docs ? od : oq) + chunk;
   }
   // the slice stream: (tile, slice) of the next slice to ISSUE, kept incrementally
   int is_ti = 0, is_s = 0;
@@ -182,21 +185,15 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
   };
   auto issue = [&](int g) __attribute__((always_inline)) {  // issues slice g of this workgroup's stream (called with g = 0, 1, 2, ...)
     if (is_s == 0) issue_tile_setup();
-    char* const dst = lds + (g % NST) * STAGE + wave * 1024;
-    const char* const dbase = is_dbase + is_s * 64;
-    const char* const qbase = is_qbase + is_s * 64;
+    char* const dst = lds + (g % NST) * STAGE + ((fetch_docs ? 0 : NAI) + hw) * 1024;
+    const char* const base = (fetch_docs ? is_dbase : is_qbase) + is_s * 64;
+    if (fetch_docs) {
 #pragma unroll
-    for (int j = 0; j < NMAX; ++j) {
-      const int ins = wave + WV * j;                                           // wave-uniform
-      if (ins >= NI) break;
-      const char* g_ptr;
-      if (j < NAI / WV) {                                                     // (doc rows = the first 8 R instructions)
-        g_ptr = dbase + off[j];
-      } else {
-        const int lr = 16 * ins + (lane >> 2);
-        g_ptr = qbase + (((lr - TM) >> 5) < is_nvalid ? off[j] : off0[j]);   // slots past nq re-read slot 0
-      }
-      __builtin_amdgcn_global_load_lds(GPTR(g_ptr), LPTR(dst + j * (WV * 1024)), 16, 0, 0);
+      for (int j = 0; j < NDA; ++j) __builtin_amdgcn_global_load_lds(GPTR(base + off[j]), LPTR(dst + j * (HW * 1024)), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDB; ++j)  // (16 rows = half a query slot: the slot number is wave-uniform; slots past nq re-read slot 0)
+        __builtin_amdgcn_global_load_lds(GPTR(base + (((hw + HW * j) >> 1) < is_nvalid ? off[j] : off[NDB + j])), LPTR(dst + j * (HW * 1024)), 16, 0, 0);
     }
     if (++is_s == nslices) { is_s = 0; ++is_ti; }
   };
@@ -270,8 +267,8 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
   if (total > 0 && masked) issue_masks(0);
   if (total > 0) {  // slice 0 for everybody, its first fragments on their way
     if (masked && wave >= WV - 2) wait_vmcnt<0>();  // (their mask rows sit behind the slices in the queue: once, at start)
-    else if (total > 2) { if (my_ndma == NMAX) wait_vmcnt<2 * NMAX>(); else wait_vmcnt<2 * NMAX - 2>(); }
-    else if (total > 1) { if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>(); }
+    else if (total > 2) { if (fetch_docs) wait_vmcnt<2 * NDA>(); else wait_vmcnt<2 * NDB>(); }
+    else if (total > 1) { if (fetch_docs) wait_vmcnt<NDA>(); else wait_vmcnt<NDB>(); }
     else wait_vmcnt<0>();
     wg_barrier();
     load_frags(0, 0, 0);
@@ -287,7 +284,7 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
     int s, ti;
     bool first, do_issue, do_masks, vm_all;
     char* dma_dst;
-    const char *dma_db, *dma_qb;
+    const char* dma_src;  // doc rows or query rows of slice g + 3, by the wave's half
     int nvalid;
     uint32_t a1, b1, a0, b0;
   };
@@ -302,12 +299,11 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
     t.do_masks = masked && t.first && g > 0;  // (tile 0's mask rows are issued in the prologue)
     t.vm_all = g + 2 >= total;
     t.dma_dst = nullptr;
-    t.dma_db = t.dma_qb = nullptr;
+    t.dma_src = nullptr;
     if (t.do_issue) {
       if (is_s == 0) issue_tile_setup();
-      t.dma_dst = lds + ((g + 3) % NST) * STAGE + wave * 1024;
-      t.dma_db = is_dbase + is_s * 64;
-      t.dma_qb = is_qbase + is_s * 64;
+      t.dma_dst = lds + ((g + 3) % NST) * STAGE + ((fetch_docs ? 0 : NAI) + hw) * 1024;
+      t.dma_src = (fetch_docs ? is_dbase : is_qbase) + is_s * 64;
       if (++is_s == nslices) { is_s = 0; ++is_ti; }
     }
     t.nvalid = is_nvalid;
@@ -327,38 +323,36 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
   for (int g = 0; g < total; ++g) {
     const int s = cur.s, ti = cur.ti;
     // slice g + 1 has landed: this wave's part (counted: the instructions of slice g + 2 may still be in flight.  Loads retire
-    // in order, so "at most my_ndma outstanding" implies slice g + 1 is in whatever the epilogue's younger stores and the
+    // in order, so "at most one slice's worth outstanding" implies slice g + 1 is in whatever the epilogue's younger stores and the
     // mask rows are doing: at worst the wait runs a few instructions into slice g + 2), then everybody's.  The barrier also
     // says: every wave is done reading slice g - 1, whose stage slice g + 3 overwrites.
     AP_STAMP_TOP();
-    if (cur.vm_all) wait_vmcnt<0>(); else if (my_ndma == NMAX) wait_vmcnt<NMAX>(); else wait_vmcnt<NMAX - 1>();
+    if (cur.vm_all) wait_vmcnt<0>(); else if (fetch_docs) wait_vmcnt<NDA>(); else wait_vmcnt<NDB>();
     AP_STAMP(1);
     wg_barrier();
     AP_STAMP(2);
     // One slice = two k-steps of R QB MFMAs, with the R + QB fragment reads of the next k-step and the LDS-DMA
     // instructions of slice g + 3 between them.
     constexpr int NM = RW * QB, NF = RW + QB;
-    constexpr int SLOTS = NM > NF ? NM - NF : 1, PER = (NMAX + SLOTS - 1) / SLOTS;  // DMA instructions per late MFMA
-    // The two waves of a SIMD (w and w + WV / 2) issue their LDS-DMA instructions in DIFFERENT k-steps: an LDS-DMA
-    // instruction holds the issuing wave for 100-180 cycles (stamped: k-step 0 with this wave's 4-5 instructions took
-    // 780-1080 cycles, k-step 1 without them 200-260), and with both partners stalled at the same point of the slice
-    // nobody fed the matrix pipe meanwhile.
-    const bool do_issue0 = cur.do_issue && wave < WV / 2, do_issue1 = cur.do_issue && wave >= WV / 2;
+    constexpr int SLOTS = NM > NF ? NM - NF : 1;  // MFMAs of a k-step that have no fragment read behind them
+    constexpr int PER_A = (NDA + SLOTS - 1) / SLOTS, PER_B = (NDB + SLOTS - 1) / SLOTS;  // LDS-DMA instructions per such MFMA
+    // The two waves of a SIMD (w and w + HW) issue their LDS-DMA instructions in DIFFERENT k-steps -- the doc-row waves in
+    // k-step 0, the query-row waves in k-step 1: an LDS-DMA instruction holds the issuing wave for 100-180 cycles (stamped:
+    // a k-step with 4-5 of them took 780-1080 cycles, one without 200-260), and with both partners stalled at the same
+    // point of the slice nobody fed the matrix pipe meanwhile.  The doc rows are 2/3 of a slice: k-step 1 also carries
+    // the next iteration's bookkeeping.
+    const bool do_issue0 = cur.do_issue && fetch_docs, do_issue1 = cur.do_issue && !fetch_docs;
     const bool first = cur.first;
     char* const dma_dst = cur.dma_dst;
-    const char* const dma_db = cur.dma_db;
-    const char* const dma_qb = cur.dma_qb;
-// LDS-DMA instruction j of this wave: image rows 16 (wave + 8 j) ...  The doc rows are the first 8 R instructions, so
-// "doc or query rows" depends on j alone; only the last j can fall off the end of the image (runtime test on the wave)
-#define AP_DMA(j)                                                                                                     \
+    const char* const dma_src = cur.dma_src;
+#define AP_DMA_A(j)                                                                                                   \
   do {                                                                                                                \
-    if (AP_ABLATE_DMA) break;                                                                                         \
-    if ((j) < NI / WV || wave < NI - WV * (j)) {                                                                      \
-      const char* gp_;                                                                                                \
-      if ((j) < NAI / WV) gp_ = dma_db + off[j];                                                                      \
-      else gp_ = dma_qb + ((((16 * (wave + WV * (j)) + (lane >> 2)) - TM) >> 5) < is_nvalid_cur ? off[j] : off0[j]);  \
-      __builtin_amdgcn_global_load_lds(GPTR(gp_), LPTR(dma_dst + (j) * (WV * 1024)), 16, 0, 0);                     \
-    }                                                                                                                 \
+    if (!AP_ABLATE_DMA) __builtin_amdgcn_global_load_lds(GPTR(dma_src + off[j]), LPTR(dma_dst + (j) * (HW * 1024)), 16, 0, 0); \
+  } while (0)
+#define AP_DMA_B(j)                                                                                                   \
+  do {                                                                                                                \
+    if (!AP_ABLATE_DMA)                                                                                               \
+      __builtin_amdgcn_global_load_lds(GPTR(dma_src + (((hw + HW * (j)) >> 1) < is_nvalid_cur ? off[j] : off[NDB + (j)])), LPTR(dma_dst + (j) * (HW * 1024)), 16, 0, 0); \
   } while (0)
 #define AP_MFMA(set, i, c0)                                                                                           \
   do {                                                                                                                \
@@ -385,9 +379,9 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
     } else if (i < NF) {                                                                                              \
       asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= RW && i < NF ? i - RW : 0]) : "v"(b1), "n"((i - RW) * 2048)); \
     } else if (do_issue0) {                                                                                           \
-      _Pragma("unroll") for (int t = 0; t < PER; ++t) {                                                               \
-        const int j = (i - NF) * PER + t;                                                                             \
-        if (j < NMAX) AP_DMA(j < NMAX ? j : 0);                                                                       \
+      _Pragma("unroll") for (int t = 0; t < PER_A; ++t) {                                                             \
+        const int j = (i - NF) * PER_A + t;                                                                           \
+        if (j < NDA) AP_DMA_A(j < NDA ? j : 0);                                                                       \
       }                                                                                                               \
     }                                                                                                                 \
   }
@@ -401,7 +395,7 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
     }
     if (NM <= NF && do_issue0) {
 #pragma unroll
-      for (int j = 0; j < NMAX; ++j) AP_DMA(j);
+      for (int j = 0; j < NDA; ++j) AP_DMA_A(j);
     }
     AP_STAMP(4);
     wait_frags(1);
@@ -415,9 +409,9 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
       else if (i < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= RW && i < NF ? i - RW : 0]) : "v"(b0), "n"((i - RW) * 2048));
       else if (do_issue1) {
 #pragma unroll
-        for (int t = 0; t < PER; ++t) {
-          const int j = (i - NF) * PER + t;
-          if (j < NMAX) AP_DMA(j < NMAX ? j : 0);
+        for (int t = 0; t < PER_B; ++t) {
+          const int j = (i - NF) * PER_B + t;
+          if (j < NDB) AP_DMA_B(j < NDB ? j : 0);
         }
       }
       if (i == (NM > 2 ? 2 : NM - 1)) nxt = prep(g + 1);  // the next iteration's bookkeeping, under this k-step's MFMAs
@@ -429,9 +423,10 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
     }
     if (NM <= NF && do_issue1) {
 #pragma unroll
-      for (int j = 0; j < NMAX; ++j) AP_DMA(j);
+      for (int j = 0; j < NDB; ++j) AP_DMA_B(j);
     }
-#undef AP_DMA
+#undef AP_DMA_A
+#undef AP_DMA_B
 #undef AP_MFMA
     AP_STAMP(6);
     if (s + 1 < nslices) {
@@ -442,6 +437,19 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
     // ---- epilogue of tile ti: similarities complete ----------------------------------------------------------------
     const int u = l + ti * nl;
     const int d = tile_doc(u), q0 = tile_q0(u);
+    // What the d_mask words of this wave's 32-row blocks are, block by block (wave-uniform): all 1 (a token row of the
+    // doc: nothing to multiply), all 0 (padding inside Ld: every similarity is 0, the block's first row is its only
+    // candidate), all NaN (tile padding past Ld: no candidate), or mixed.  With the reference's prefix masks
+    // (tokenizers.py:57) at most one block of a doc is mixed.
+    enum { BLK_MIXED = 0, BLK_ONES = 1, BLK_ZEROS = 2, BLK_NONE = 3 };
+    int kind[RW];
+#pragma unroll
+    for (int b = 0; b < RW; ++b) {
+      const float w = dm_lds[(wm * RW + b) * 32 + r];
+      const bool ones = __builtin_amdgcn_ballot_w64(w == 1.0f) == ~0ull, zeros = __builtin_amdgcn_ballot_w64(w == 0.0f) == ~0ull;
+      const bool nans = __builtin_amdgcn_ballot_w64(w != w) == ~0ull;
+      kind[b] = ones ? BLK_ONES : zeros ? BLK_ZEROS : nans ? BLK_NONE : BLK_MIXED;
+    }
 #pragma unroll
     for (int q = 0; q < QB; ++q) {  // one query at a time: the accumulators leave few registers for anything else
       const int qq = q0 + wn * QB + q;
@@ -454,31 +462,42 @@ __global__ void __launch_bounds__(WV * 64) k_maxsim_allpairs(const AllPairsArgs 
       float best = NEG_INF;
       int bidx = 0;  // position b * 16 + v of the winner among this lane's values (compile-time numbers: no arithmetic per
                      // value; turned into a row number once, below)
-      // (two copies of the scan, chosen per wave: a conditional multiplication inside one copy cost 12 registers -> spills)
+      // (copies of the scan chosen by wave-uniform branches: a conditional multiplication inside one copy cost 12
+      //  registers -> spills)
+#define AP_PICK(sim_, pos_)                                                                                           \
+  do {                                                                                                                \
+    const bool better = (sim_) > best; /* strict >: the first maximal token wins (torch.max); a NaN never does */      \
+    best = better ? (sim_) : best;                                                                                    \
+    if (AM) bidx = better ? (pos_) : bidx;                                                                            \
+  } while (0)
 #define AP_SCAN(PREMUL)                                                                                               \
   _Pragma("unroll") for (int b = 0; b < RW; ++b) {                                                                    \
-    int rowbase = (wm * RW + b) * 32 + 4 * hh;                                                                        \
-    /* opaque: otherwise the mask words are shared by the QB unrolled query iterations and stay live across them */   \
-    asm volatile("" : "+v"(rowbase));                                                                                 \
-    /* d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait (a read + wait per pair of */ \
-    /* rows made the epilogue cost as much as the whole K loop: 14 us per tile); NaN past Ld (tile padding) */        \
-    f32x4 d4[4];                                                                                                      \
-    _Pragma("unroll") for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm_lds + rowbase + 8 * k);                  \
-    _Pragma("unroll") for (int v = 0; v < 16; v += 2) { /* rows in increasing order, two at a time (v_pk_mul_f32) */  \
-      f32x2 w = {d4[v >> 2][v & 3], d4[v >> 2][(v & 3) + 1]};                                                         \
-      if (PREMUL) w *= qm;                                                                                            \
-      f32x2 sim = {acc[b][q][v], acc[b][q][v + 1]};                                                                   \
-      sim *= w; /* . d_mask (. q_mask: in w, or after the scan) */                                                    \
-      _Pragma("unroll") for (int e = 0; e < 2; ++e) {                                                                 \
-        const bool better = sim[e] > best; /* strict >: the first maximal token wins (torch.max); a NaN never does */ \
-        best = better ? sim[e] : best;                                                                                \
-        if (AM) bidx = better ? b * 16 + v + e : bidx;                                                                \
+    if (!PREMUL && kind[b] == BLK_ONES) {                                                                             \
+      _Pragma("unroll") for (int v = 0; v < 16; ++v) AP_PICK(acc[b][q][v], b * 16 + v);                               \
+    } else if (!PREMUL && kind[b] == BLK_ZEROS) {                                                                     \
+      AP_PICK(0.0f, b * 16);                                                                                          \
+    } else if (kind[b] != BLK_NONE) {                                                                                 \
+      int rowbase = (wm * RW + b) * 32 + 4 * hh;                                                                      \
+      /* opaque: otherwise the mask words are shared by the QB unrolled query iterations and stay live across them */ \
+      asm volatile("" : "+v"(rowbase));                                                                               \
+      /* d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait (a read + wait per pair  */ \
+      /* of rows made the epilogue cost as much as the whole K loop: 14 us per tile); NaN past Ld (tile padding) */    \
+      f32x4 d4[4];                                                                                                    \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm_lds + rowbase + 8 * k);                \
+      _Pragma("unroll") for (int v = 0; v < 16; v += 2) { /* rows in increasing order, two at a time (v_pk_mul_f32) */ \
+        f32x2 w = {d4[v >> 2][v & 3], d4[v >> 2][(v & 3) + 1]};                                                       \
+        if (PREMUL) w *= qm;                                                                                          \
+        f32x2 sim = {acc[b][q][v], acc[b][q][v + 1]};                                                                 \
+        sim *= w; /* . d_mask (. q_mask: in w, or after the scan) */                                                  \
+        AP_PICK(sim[0], b * 16 + v);                                                                                  \
+        AP_PICK(sim[1], b * 16 + v + 1);                                                                              \
       }                                                                                                               \
     }                                                                                                                 \
     __builtin_amdgcn_sched_barrier(0); /* (one block's mask words at a time) */                                       \
   }
       if (premul) { AP_SCAN(true) } else { AP_SCAN(false) }
 #undef AP_SCAN
+#undef AP_PICK
       // (Q q_mask) . (D d_mask), BaseModel.py:41-43.  q_mask = 0 makes every similarity of the token 0: the first row wins
       const bool qzero = !premul && qm == 0.0f;
       if (!premul) best = qzero ? 0.0f : best * qm;

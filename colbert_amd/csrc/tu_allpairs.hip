@@ -18,31 +18,25 @@ int cu_count() {  // workgroups are persistent, one per CU; the XCD-aware tile w
   return cus[dev];
 }
 
-template <int DT, int R, int QB, bool AM, int WV>
+template <int DT, int R, int QB, bool AM>
 int launch_r(const AllPairsArgs& a, hipStream_t st) {
 #ifdef MAXSIM_DIAG
   constexpr int ldsb = 4 * (128 * R + 64 * QB) * 64 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4 + 2 * 24 * 9 * 8;
 #else
   constexpr int ldsb = 4 * (128 * R + 64 * QB) * 64 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4;
 #endif
-  auto kern = k_maxsim_allpairs<DT, R, QB, AM, WV>;
+  auto kern = k_maxsim_allpairs<DT, R, QB, AM>;
   int rc = allow_lds(kern, ldsb);
   if (rc) return rc;
-  hipLaunchKernelGGL(kern, dim3((unsigned)cu_count()), dim3(WV * 64), ldsb, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)cu_count()), dim3(512), ldsb, st, a);
   return check_launch();
 }
 
 template <int DT, bool AM>
 int launch_dt(const AllPairsArgs& a, hipStream_t st) {
-  const int wv = MAXSIM_KNOB("MAXSIM_ALLPAIRS_WAVES", 8);
-  if (wv == 4) {
-    if (a.Ld <= 128) return launch_r<DT, 1, 4, AM, 4>(a, st);
-    if (a.Ld <= 256) return launch_r<DT, 2, 3, AM, 4>(a, st);
-    return launch_r<DT, 3, 2, AM, 4>(a, st);
-  }
-  if (a.Ld <= 128) return launch_r<DT, 1, 4, AM, 8>(a, st);
-  if (a.Ld <= 256) return launch_r<DT, 2, 4, AM, 8>(a, st);
-  return launch_r<DT, 3, 3, AM, 8>(a, st);
+  if (a.Ld <= 128) return launch_r<DT, 1, 4, AM>(a, st);
+  if (a.Ld <= 256) return launch_r<DT, 2, 4, AM>(a, st);
+  return launch_r<DT, 3, 3, AM>(a, st);
 }
 
 }  // namespace

@@ -444,6 +444,58 @@ def test_allpairs_kernel_matches_streaming_kernel_and_oracle(ca, cfg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("Ld,dt", [(128, torch.float16), (250, torch.bfloat16), (384, torch.bfloat16)])
+def test_allpairs_kernel_prefix_masks(ca, Ld, dt):
+    """The masks the reference actually builds (tokenizers.py:57: ones up to the doc's length, zeros after): the kernel's
+    epilogue treats 32-row blocks of all ones / all zeros / tile padding without a multiplication.  Lengths on and
+    around the block boundaries, length 1, full length and an all-zero row; against the streaming kernel (int64 masks)
+    and the oracle, arg-max included (a doc's zero-weight rows have similarity 0: they win over negative similarities,
+    and the first of them is the arg-max)."""
+    from oracle.maxsim_oracle import ref_score
+    from colbert_amd.scoring import _DT, _MDT
+    L = ca._lib.lib
+    gen = torch.Generator().manual_seed(5 + Ld)
+    nq, nd, Lq, h = 20, 72, 32, 64
+    Q = nrm(gen, nq, Lq, h).to(dt)
+    D = nrm(gen, nd, Ld, h).to(dt)
+    lens = torch.randint(1, Ld + 1, (nd,), generator=gen)
+    edge = [0, 1, 31, 32, 33, 63, 64, 65, 96, 127, 128, Ld - 1, Ld]
+    lens[:len(edge)] = torch.tensor([min(e, Ld) for e in edge])
+    dm = (torch.arange(Ld)[None, :] < lens[:, None]).long()
+    qlen = torch.randint(1, Lq + 1, (nq,), generator=gen)
+    qm = (torch.arange(Lq)[None, :] < qlen[:, None]).long()
+    Qd, Dd = Q.cuda(), D.cuda()
+    res = {}
+    for name, mt in (("gemm", torch.float32), ("stream", torch.int64)):
+        qmd, dmd = qm.to(mt).cuda(), dm.to(mt).cuda()
+        out = torch.empty(nq, nd, device="cuda")
+        arg = torch.full((nq, nd, Lq), -7, dtype=torch.int32, device="cuda")
+        rc = L.maxsim_score_dense_fwd(Qd.data_ptr(), Dd.data_ptr(), qmd.data_ptr(), dmd.data_ptr(), nq, nd, Lq, Ld, h,
+                                      _DT[dt], _MDT[mt], out.data_ptr(), arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        res[name] = (out.cpu(), arg.cpu())
+    exp = ref_score(Q.float(), D.float(), qm, dm)
+    torch.testing.assert_close(res["gemm"][0], exp, rtol=0, atol=ATOL16)
+    torch.testing.assert_close(res["gemm"][0], res["stream"][0], rtol=0, atol=ATOL16)
+    sim = torch.einsum("qmh,dnh->qdmn", (Q.float() * qm[..., None]).double(), (D.float() * dm[..., None]).double())
+    top2 = sim.topk(2, dim=-1).values
+    live = (qm == 1)[:, None, :].expand(nq, nd, Lq)
+    clear = (top2[..., 0] - top2[..., 1] > 1e-4) & live
+    # the maximum is a zero-weight row's exact 0 (every live similarity negative): the first such row
+    zero_wins = live & (top2[..., 0] == 0) & (lens < Ld)[None, :, None]
+    ref_idx = sim.argmax(-1).to(torch.int32)
+    first_zero = lens.to(torch.int32)[None, :, None].expand(nq, nd, Lq)
+    for name in ("gemm", "stream"):
+        got = res[name][1]
+        assert bool((got >= 0).all()) and bool((got < Ld).all()), name
+        assert bool((got[clear] == ref_idx[clear]).all()), name
+        assert bool((got[zero_wins] == first_zero[zero_wins]).all()), name
+        assert bool((got[~live] == 0).all()), name
+    assert float(clear.float().mean()) > 0.3
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Ld", [100, 200, 300])
 def test_allpairs_kernel_general_float_masks(ca, Ld):
     """Masks the reference never builds but its interface allows: fractional, negative and zero float32 weights on both
