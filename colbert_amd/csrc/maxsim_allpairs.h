@@ -1,5 +1,5 @@
 // maxsim_allpairs.h -- the all-pairs (training-form) MaxSim as a register-blocked, K-sliced GEMM with a fused
-// max / arg-max / sum epilogue: 16-bit Q and D of any width h that is a multiple of 32 (the reference trains at dim 768,
+// max / arg-max / sum epilogue: 16-bit Q and D of any width h that is a multiple of 64 (the reference trains at dim 768,
 // proj_conf/dense.yaml:8), Lq <= 32 query tokens, Ld <= 384 doc tokens (doc_maxlen, dense.yaml:7).
 //
 // Reference: BaseModel.score (colbert/modeling/BaseModel.py:39-46) as ColbertModel.forward calls it on the gathered batch
@@ -9,25 +9,31 @@
 // to exist: only 148 k scores and 4.7 M arg-max indices leave the kernel.
 //
 // The streaming kernel (maxsim_stream_bigh.h) computes this with one wave per 32-row doc tile and whole query images
-// in LDS: every 8 KB A fragment set is read for QB x 8 MFMAs, 2 KB of LDS traffic per MFMA at QB = 2 -- the LDS peak
-// (128 B/clk/CU) at full matrix rate, measured 22 % of the bf16 peak.  Here the blocking is a GEMM's:
+// in LDS: 2 KB of LDS traffic per MFMA, measured 22 % of the bf16 peak.  Here the blocking is a GEMM's:
 //   workgroup  8 waves = 4 (doc rows) x 2 (queries); tile = ONE doc (up to 128 R rows, R = 1..3) x 2 QB queries
 //   wave       R row blocks x QB queries of 32x32x16 MFMAs: R + QB fragment reads (1 KB each) per R QB MFMAs, 16 R QB
 //              accumulator registers.  (R, QB) = (1, 4), (2, 4), (3, 3): with 8 waves a wave has 256 registers, and
-//              3 x 4 blocks (192 accumulators) spilled; 3 x 3 = 0.67 KB of LDS reads per MFMA
-//   K          sliced by 32 dims: a slice is (128 R + 64 QB) rows x 64 B, fetched by LDS-DMA (global_load_lds_dwordx4, no
-//              register staging; source addresses = wave-uniform 64-bit base + a 32-bit lane offset computed once) into a
-//              4-stage ring: slice g being read, g + 1 complete (its first fragments are requested across the barrier),
-//              g + 2 and g + 3 in flight.  ONE bare s_barrier per slice (__syncthreads would wait for every DMA in
-//              flight), counted s_waitcnt vmcnt for the slice that must have landed; fragment reads are ds_read_b128 by
-//              hand, double-buffered, placed between the MFMAs of the previous k-step
-//   tiles      workgroups are persistent (one per CU: ~150 KB of LDS) and walk (doc, query block) tiles; the ring runs
-//              across tile boundaries, so the next tile's first slices arrive during the epilogue.  XCD x takes the docs
-//              x, x + 8, ... and walks their query blocks in order: the ~32 workgroups of an XCD work on one or two docs at
-//              a time (the doc comes from that XCD's L2; the 13 MB of queries from the Infinity Cache)
-//   epilogue   per lane and query: running (max, first index) over its rows in increasing row order, lane halves combined
-//              with v_permlane32_swap, the four row-waves through LDS; masks multiply the finished similarities (exact
-//              for 0/1 masks, the only ones training uses: tokenizers.py:36,57); 0-padding rows past Ld never win.
+//              3 x 4 blocks (192 accumulators) spilled
+//   K          sliced by 64 dims: a slice is (128 R + 64 QB) rows x 128 B -- whole cache lines: an LDS-DMA instruction
+//              (buffer_load_dwordx4 ... lds, 1 KB, no register staging) that takes 8 rows x 128 B costs the CU's memory
+//              pipeline 12 cycles, one that takes 16 rows x 64 B (a 32-dim slice) 18 (tools/micro/lds_dma_rate.hip) --
+//              into a 2-stage ring: one slice being read, the next in flight for the four k-steps of the current one.
+//              Addresses are a buffer descriptor over the whole tensor + ONE 32-bit lane offset + a wave-uniform term:
+//              what lies past the end of the tensor reads as 0 (rows past a doc's Ld and query slots past nq need no
+//              clamping: they are tile padding, weighted NaN / 0 in the epilogue)
+//   loop       ONE bare s_barrier per slice (__syncthreads would be a fence: see wg_barrier); fragment reads are
+//              ds_read_b128 by hand, double-buffered by k-step and placed between the MFMAs of the previous k-step; the
+//              two waves of a SIMD (w, w + 4) issue their LDS-DMA instructions in DIFFERENT k-steps (an LDS-DMA
+//              instruction holds its wave for 60-180 cycles; matrix beside memory is what two waves of a SIMD overlap)
+//   tiles      workgroups are persistent (one per CU: ~152 KB of LDS) and walk (doc, query block) tiles; the ring runs
+//              across tile boundaries.  XCD x takes the docs x, x + 8, ... and walks their query blocks in order: the ~32
+//              workgroups of an XCD work on one or two docs at a time (the doc comes from that XCD's L2; the 13 MB of
+//              queries from the Infinity Cache)
+//   epilogue   per lane and query: running (max, first position) over its rows in increasing row order, lane halves
+//              combined with v_permlane32_swap, the four row-waves through LDS; d_mask multiplies the finished
+//              similarities block by block (skipped for blocks of all ones / all zeros / tile padding), a non-negative
+//              q_mask the maximum (exact for 0/1 masks, the only ones training uses: tokenizers.py:36,57; a negative
+//              weight takes the multiplication back into every similarity)
 #pragma once
 #include "maxsim_common.h"
 
@@ -41,32 +47,7 @@ struct AllPairsArgs {
   float* scores;       // [nq, nd]
   int32_t* argmax;     // [nq, nd, Lq] (AM)
   int mask_dtype, nq, nd, Lq, Ld, h;
-#ifdef MAXSIM_DIAG
-  int stamp_g0, stamp_wg;  // diagnostic build: s_memtime stamps of slices stamp_g0 .. + 23 of workgroup stamp_wg
-#endif
 };
-
-#ifdef MAXSIM_DIAG
-// In-kernel stamps (diagnostic build only; tools/allpairs_stamps.py reads them): [2 waves][24 slices][9 points].
-// A stamp is ONE scalar instruction whose result is not waited for (a wait would also drain the LDS reads in flight).
-// The nine results of a slice -- the ninth is the top of the NEXT iteration -- are stored right after that top stamp, so
-// the cost of storing them falls into the first segment of the next slice (top -> vmcnt wait) and nowhere else.  Kept in
-// LDS while the loop runs (a global store would count in vmcnt and move the loop's counted waits), dumped at the end.
-__device__ uint64_t g_ap_stamps[2 * 24 * 9];
-#define AP_STAMP(k) asm volatile("s_memtime %0" : "=s"(tS[k]))
-#define AP_STAMP_TOP()                                                                           \
-  do {                                                                                           \
-    AP_STAMP(8);                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                           \
-    if (stamp_w >= 0 && g > a.stamp_g0 && g <= a.stamp_g0 + 24 && lane < 9)                      \
-      st_lds[(stamp_w * 24 + (g - 1 - a.stamp_g0)) * 9 + lane] = lane == 0 ? tS[0] : lane == 1 ? tS[1] : lane == 2 ? tS[2] : lane == 3 ? tS[3] : lane == 4 ? tS[4] : lane == 5 ? tS[5] : lane == 6 ? tS[6] : lane == 7 ? tS[7] : tS[8]; \
-    tS[0] = tS[8];                                                                               \
-    tS[7] = 0;                                                                                   \
-  } while (0)
-#else
-#define AP_STAMP(k) do {} while (0)
-#define AP_STAMP_TOP() do {} while (0)
-#endif
 
 template <int CTRL>
 __device__ __forceinline__ float ap_dpp(float v) {
@@ -74,9 +55,8 @@ __device__ __forceinline__ float ap_dpp(float v) {
 }
 
 // The bare hardware barrier.  __syncthreads() is a workgroup fence + barrier, and the fence waits for EVERY outstanding
-// memory operation of the wave (s_waitcnt vmcnt(0)) -- including the LDS-DMA slices this kernel keeps in flight on
-// purpose: with it the ring never ran ahead and every slice exposed the full memory latency (35 % MFMA busy).  The loop
-// orders its data by hand: counted vmcnt for the slice that must have landed, then the barrier.
+// memory operation of the wave (s_waitcnt vmcnt(0)) at a point the compiler chooses; the loop orders its data by hand:
+// this wave's part of the next slice has landed (vmcnt) / its LDS accesses are done (lgkmcnt), then the barrier.
 __device__ __forceinline__ void wg_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_barrier();
@@ -89,59 +69,52 @@ __device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are d
   asm volatile("" ::: "memory");
 }
 
-// (timing experiments of the diagnostic build: -DAP_ABLATE_DMA=1 drops the loop's LDS-DMA instructions, -DAP_ABLATE_MFMA=1
-//  its MFMAs; results are then wrong, only the time is of interest)
+// (timing experiments: -DAP_ABLATE_DMA=1 drops the loop's LDS-DMA instructions, -DAP_ABLATE_MFMA=1 its MFMAs; results
+//  are then wrong, only the time is of interest)
 #ifndef AP_ABLATE_DMA
 #define AP_ABLATE_DMA 0
 #endif
 #ifndef AP_ABLATE_MFMA
 #define AP_ABLATE_MFMA 0
 #endif
+// k-steps (0..3) in which the first-half waves (doc rows) and the second-half waves (query rows) issue their LDS-DMA
+// instructions of the next slice: the first half in A0 and A0 + 1, the second half in B0
+#ifndef AP_DMA_A0
+#define AP_DMA_A0 0
+#endif
+#ifndef AP_DMA_B0
+#define AP_DMA_B0 2
+#endif
 
 template <int DT, int R, int QB, bool AM>
 __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
-  constexpr int WV = 8;  // waves: 4 (doc rows) x 2 (queries).  (Four waves of twice the rows, one per SIMD with 512 registers,
-                         // were slower: the accumulators must then fit the 256 AGPRs, i.e. 6 x 2 blocks at best.)
   static_assert(DT == MAXSIM_F16 || DT == MAXSIM_BF16, "16-bit operands");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int NQ = 2 * QB;                     // queries of a tile
   constexpr int TM = 128 * R, TN = 32 * NQ;      // tile rows (doc tokens) / columns (query tokens)
   constexpr int ROWS = TM + TN;                  // rows of a K slice image
-  constexpr int STAGE = ROWS * 64;               // bytes: 32 dims x 2 B per row
-  constexpr int NST = 4;                         // ring stages: slice g being read, g + 1 ready (its first fragments are
-                                                 // prefetched across the barrier), g + 2 and g + 3 in flight
-  constexpr int NI = ROWS / 16;                  // LDS-DMA instructions per slice (16 rows each)
-  constexpr int WM = WV / 2;                     // row-waves
-  constexpr int RW = 4 * R / WM;                 // 32-row blocks of a wave
-  constexpr int NAI = TM / 16;                   // instructions < NAI move doc rows, the others query rows
-  constexpr int HW = WV / 2;                     // waves 0 .. HW - 1 fetch the doc rows, HW .. WV - 1 the query rows: a wave
-  constexpr int NDA = NAI / HW;                  // and its SIMD partner (w, w + HW) sit in different halves
-  constexpr int NDB = (NI - NAI) / HW;           // LDS-DMA instructions per slice of a doc-row wave (2 R) / query-row wave (QB)
-  constexpr int NOFF = NDA > 2 * NDB ? NDA : 2 * NDB;
-  float* const ex_v = (float*)(lds + NST * STAGE);      // [NQ][4 wm][32]: per-wave (max) ...
+  constexpr int STAGE = ROWS * 128;              // bytes: 64 dims x 2 B per row
+  constexpr int KS = 4;                          // k-steps (16 dims) of a slice
+  constexpr int NAI = TM / 8;                    // LDS-DMA instructions (8 rows each) < NAI move doc rows, the others query rows
+  constexpr int NDA = NAI / 4;                   // ... per slice of a first-half wave (the doc rows: 4 R)
+  constexpr int NDB = (TN / 8) / 4;              // ... of a second-half wave (the query rows: 2 QB)
+  constexpr int NM = R * QB, NF = R + QB;        // MFMAs / fragment reads of a k-step
+  float* const ex_v = (float*)(lds + 2 * STAGE);        // [NQ][4 row-waves][32]: per-wave (max) ...
   int* const ex_i = (int*)(ex_v + NQ * 4 * 32);         // ... and (first index)
   float* const dm_lds = (float*)(ex_i + NQ * 4 * 32);   // [TM]: d_mask row of the tile's doc
   float* const qm_lds = dm_lds + TM;                    // [NQ * 32]: q_mask rows of the tile's queries
   // (LDS-space views for the DMA destinations, cast here in uniform control flow: the generic -> LDS cast inside a
   //  divergent branch trips a code-generation bug of this compiler)
   typedef __attribute__((address_space(3))) char* lds_ptr_t;
-  const lds_ptr_t dm_dst = (lds_ptr_t)LPTR(dm_lds), qm_dst = (lds_ptr_t)LPTR(qm_lds);
+  const lds_ptr_t lds3 = (lds_ptr_t)LPTR(lds), dm_dst = (lds_ptr_t)LPTR(dm_lds), qm_dst = (lds_ptr_t)LPTR(qm_lds);
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = uni(tid >> 6), wm = wave & (WM - 1), wn = wave / WM;
+  const int wave = uni(tid >> 6), wm = wave & 3, wn = wave >> 2;
+  const bool first_half = wn == 0;  // waves 0-3 fetch the doc rows, waves 4-7 (their SIMD partners) the query rows
   const int r = lane & 31, hh = lane >> 5;
-  const int nslices = a.h >> 5;
-  const int64_t rowb = (int64_t)a.h * 2;
+  const int nslices = a.h >> 6;
+  const uint32_t rowb = (uint32_t)a.h * 2;
   const int nqb = (a.nq + NQ - 1) / NQ;
-  const bool fetch_docs = wave < HW;
-  const int hw = wave & (HW - 1);
-#ifdef MAXSIM_DIAG
-  uint64_t* const st_lds = (uint64_t*)(qm_lds + NQ * 32);
-  const int stamp_w = (int)blockIdx.x != a.stamp_wg ? -1 : wave == 0 ? 0 : wave == WV - 1 ? 1 : -1;
-  if ((int)blockIdx.x == a.stamp_wg) {
-    for (int i = tid; i < 2 * 24 * 9; i += WV * 64) st_lds[i] = 0;
-  }
-#endif
 
   // ---- this workgroup's tiles: XCD x = id % 8 owns docs x, x + 8, ...; its workgroups walk (doc, query block) in order
   const int x = blockIdx.x & 7, l = blockIdx.x >> 3, nl = max(1, (int)gridDim.x >> 3);
@@ -152,107 +125,39 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   const int my_tiles = l < ntx ? (ntx - l + nl - 1) / nl : 0;
   const int total = my_tiles * nslices;  // slices this workgroup streams
 
-  // ---- fetch side.  DMA instruction j of this wave moves rows 16 (wave + 8 j) .. + 15 of the slice image: lane i -> row
-  //      + i / 4, 16-byte position i % 4, which receives source chunk (i % 4) ^ ((row >> 2) & 3) (fragment reads are
-  //      conflict-free).  Everything lane-dependent is a 32-bit offset computed ONCE (the address of an instruction is a
-  //      wave-uniform 64-bit base + that offset: no vector arithmetic per slice -- with two waves per SIMD in the same
-  //      phase, every VALU cycle spent here is a cycle the matrix pipe idles).
-  //      Doc-row wave hw moves image rows 16 (hw + HW j) .. + 15 (j < NDA), query-row wave hw the rows TM + 16 (hw + HW j) ..
-  //      (j < NDB).  off[j]: doc rows min(row, Ld - 1) * rowb + chunk; query rows (slot * Lq + min(token, Lq - 1)) * rowb +
-  //      chunk and, at NDB + j, the same for slot 0 (used for slots past nq in the last, partial query block).
-  uint32_t off[NOFF];
-#pragma unroll
-  for (int j = 0; j < NOFF; ++j) {
-    const int jj = fetch_docs ? j : j % NDB;
-    const int lr = 16 * (hw + HW * jj) + (lane >> 2);  // row within the doc part / the query part of the image
-    const uint32_t chunk = (uint32_t)(((lane & 3) ^ ((lr >> 2) & 3)) * 16);  // (TM % 16 == 0: the same swizzle either way)
-    const int slot = lr >> 5, t = min(lr & 31, a.Lq - 1);  // tokens past Lq re-read the last token (weight 0)
-    const uint32_t od = (uint32_t)(min(lr, a.Ld - 1) * (int)rowb);  // rows past Ld re-read the last row (never candidates)
-    const uint32_t oq = (uint32_t)(((j < NDB ? slot * a.Lq : 0) + t) * (int)rowb);
-    off[j] = (fetch_docs ? od : oq) + chunk;
-  }
-  // the slice stream: (tile, slice) of the next slice to ISSUE, kept incrementally
-  int is_ti = 0, is_s = 0;
-  const char* is_dbase = nullptr;  // D + doc * Ld * rowb
-  const char* is_qbase = nullptr;  // Q + q0 * Lq * rowb
-  int is_nvalid = 0;               // query slots of the block that exist
-  auto issue_tile_setup = [&]() __attribute__((always_inline)) {
-    const int u = l + is_ti * nl;
-    const int d = tile_doc(u), q0 = tile_q0(u);
-    is_dbase = (const char*)a.D + ((int64_t)d * a.Ld) * rowb;
-    is_qbase = (const char*)a.Q + ((int64_t)q0 * a.Lq) * rowb;
-    is_nvalid = min(NQ, a.nq - q0);
-  };
-  auto issue = [&](int g) __attribute__((always_inline)) {  // issues slice g of this workgroup's stream (called with g = 0, 1, 2, ...)
-    if (is_s == 0) issue_tile_setup();
-    char* const dst = lds + (g % NST) * STAGE + ((fetch_docs ? 0 : NAI) + hw) * 1024;
-    const char* const base = (fetch_docs ? is_dbase : is_qbase) + is_s * 64;
-    if (fetch_docs) {
-#pragma unroll
-      for (int j = 0; j < NDA; ++j) __builtin_amdgcn_global_load_lds(GPTR(base + off[j]), LPTR(dst + j * (HW * 1024)), 16, 0, 0);
-    } else {
-#pragma unroll
-      for (int j = 0; j < NDB; ++j)  // (16 rows = half a query slot: the slot number is wave-uniform; slots past nq re-read slot 0)
-        __builtin_amdgcn_global_load_lds(GPTR(base + (((hw + HW * j) >> 1) < is_nvalid ? off[j] : off[NDB + j])), LPTR(dst + j * (HW * 1024)), 16, 0, 0);
-    }
-    if (++is_s == nslices) { is_s = 0; ++is_ti; }
-  };
-
-  // ---- compute side: fragment addresses inside a stage
-  //      A fragment of row block b, k-step ks: row 32 b + r, chunk 2 ks + hh at position chunk ^ ((row >> 2) & 3)
-  const int swz = (r >> 2) & 3;
-  f32x16 acc[RW][QB];
-#pragma unroll
-  for (int b = 0; b < RW; ++b)
-#pragma unroll
-    for (int q = 0; q < QB; ++q) acc[b][q] = (f32x16)(0.0f);
-
-  // fragment sets, double-buffered: while the MFMAs of one k-step run, the next k-step's fragments are on their way from
-  // LDS (a workgroup's waves hit the barrier together; without this overlap the LDS read phase -- 96 KB per slice and CU,
-  // 768 cycles at 128 B/clk -- and the MFMA phase -- 1152 cycles per SIMD -- serialise: measured 35 % MFMA busy)
-  u32x4 fa[2][RW], fb[2][QB];
-  auto load_frags = [&](int set, int g, int ks) __attribute__((always_inline)) {
-    const char* const st = lds + (g % NST) * STAGE;
-    const int pos = ((2 * ks + hh) ^ swz) * 16;
-    // ds_read_b128 by hand: the compiler would wait for a set with s_waitcnt lgkmcnt(0) -- i.e. also for the set it has
-    // just issued -- because it cannot count LDS returns across the loop back edge; wait_frags counts them instead
-    const uint32_t aa = (uint32_t)(size_t)(st + ((wm * RW) * 32 + r) * 64 + pos - lds);
-    const uint32_t ab = (uint32_t)(size_t)(st + (TM + (wn * QB) * 32 + r) * 64 + pos - lds);
-#pragma unroll
-    for (int b = 0; b < RW; ++b) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][b]) : "v"(aa), "n"(b * 2048));
-#pragma unroll
-    for (int q = 0; q < QB; ++q) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][q]) : "v"(ab), "n"(q * 2048));
-  };
-  // every LDS read issued so far has returned (the reads of a set are issued a whole k-step before they are needed)
-  auto wait_frags = [&](int set) __attribute__((always_inline)) {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int b = 0; b < RW; ++b) asm volatile("" : "+v"(fa[set][b]));  // (the MFMAs below depend on this point)
-#pragma unroll
-    for (int q = 0; q < QB; ++q) asm volatile("" : "+v"(fb[set][q]));
-  };
+  // ---- fetch side.  An LDS-DMA instruction moves 8 rows x 128 B of the slice image: lane i -> row + i / 8, 16-byte
+  //      position i % 8, which receives source chunk (i % 8) ^ ((row >> 1) & 7): the four 16-lane groups of a fragment
+  //      read (ds_read_b128: one chunk of 32 consecutive rows) then cover all 64 banks exactly once.  First-half wave wm
+  //      moves the image rows 8 (wm + 4 j) .. + 7 (j < NDA), second-half wave wm the rows TM + 8 (wm + 4 j) .. (j < NDB):
+  //      (row >> 1) & 7 = (4 (wm & 1) + lane / 16) & 7 for every j, so the lane offset is ONE register; the rest of
+  //      the address -- tensor offset of the doc / query block, 32 j rows / query slot j, 128 B per slice -- is scalar.
+  const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(first_half ? a.D : a.Q), 0,
+      (int)(uint32_t)((uint64_t)(first_half ? (int64_t)a.nd * a.Ld : (int64_t)a.nq * a.Lq) * rowb), 0x00020000);
+  const uint32_t lane_off = (uint32_t)((first_half ? lane >> 3 : 8 * wm + (lane >> 3)) * rowb) + (first_half ? 8u * wm * rowb : 0u) +
+                            (uint32_t)((((lane & 7) ^ ((4 * (wm & 1) + (lane >> 4)) & 7))) << 4);
+  const uint32_t j_stride = first_half ? 32u * rowb : (uint32_t)a.Lq * rowb;  // doc rows 32 j / query slot j
+  const uint32_t dst_off = (uint32_t)(((first_half ? 0 : NAI) + wm) * 1024);   // instruction j lands at + 4096 j
   // masks (float32 or none -- the launcher sends other mask types to the streaming kernel): the tile's mask rows come in
-  // by LDS-DMA with the tile's first slices, like everything else.  An ordinary load anywhere in this loop would make the
-  // compiler wait for its result with s_waitcnt vmcnt(0), i.e. for every slice in flight: the ring would never run ahead
-  // (measured: that alone held the kernel at 35 % MFMA busy).
+  // by LDS-DMA with the tile's first slice, like everything else (an ordinary load in this loop would be ordered against
+  // the LDS-DMA traffic by the compiler).  Rows past Ld are tile padding: their mask word is NaN for the whole kernel,
+  // so their products are NaN and never win a `>`; without masks every real row / token weighs 1.
   const bool masked = a.mask_dtype != MAXSIM_MASK_NONE;
-  // rows past Ld are tile padding: their mask word is NaN for the whole kernel, so their products are NaN and never win a
-  // `>` (no bound test per element in the epilogue); without masks every real row / token weighs 1
-  for (int i = tid; i < TM + NQ * 32; i += WV * 64) {
+  for (int i = tid; i < TM + NQ * 32; i += 512) {
     const bool pad = i >= a.Ld && i < TM;
     if (pad || !masked) dm_lds[i] = pad ? __builtin_nanf("") : 1.0f;
   }
-  auto issue_masks = [&](int ti) __attribute__((always_inline)) {  // the last two waves, after their part of a tile's first slice
+  auto issue_masks = [&](int ti) __attribute__((always_inline)) {  // waves 6 and 7: the mask rows of tile ti
     const int u = l + ti * nl;
     const int d = tile_doc(u), q0 = tile_q0(u);
-    if (wave == WV - 2) {
+    if (wave == 6) {
 #pragma unroll
       for (int j = 0; j < TM / 64; ++j) {
         const int row = j * 64 + lane;
         if (row < a.Ld)  // (lanes past Ld stay out: their words keep the NaN)
           __builtin_amdgcn_global_load_lds(GPTR((const float*)a.d_mask + (int64_t)d * a.Ld + row), (__attribute__((address_space(3))) void*)(dm_dst + j * 256), 4, 0, 0);
       }
-    } else if (wave == WV - 1) {
+    } else if (wave == 7) {
 #pragma unroll
       for (int j = 0; j < NQ / 2; ++j) {
         const int slot = 2 * j + (lane >> 5);
@@ -261,191 +166,148 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       }
     }
   };
-  if (total > 0) issue(0);
-  if (total > 1) issue(1);
-  if (total > 2) issue(2);
-  if (total > 0 && masked) issue_masks(0);
-  if (total > 0) {  // slice 0 for everybody, its first fragments on their way
-    if (masked && wave >= WV - 2) wait_vmcnt<0>();  // (their mask rows sit behind the slices in the queue: once, at start)
-    else if (total > 2) { if (fetch_docs) wait_vmcnt<2 * NDA>(); else wait_vmcnt<2 * NDB>(); }
-    else if (total > 1) { if (fetch_docs) wait_vmcnt<NDA>(); else wait_vmcnt<NDB>(); }
-    else wait_vmcnt<0>();
-    wg_barrier();
-    load_frags(0, 0, 0);
-  }
-
-  // Per-iteration bookkeeping (loop position, which wait, the LDS-DMA bases of slice g + 3, fragment addresses): ~100 scalar
-  // and vector instructions.  A wave issues at most one instruction every 4 cycles, an MFMA keeps the matrix pipe busy for
-  // 32, and after every barrier all eight waves are in the same phase: whatever is not placed BETWEEN a wave's MFMAs in
-  // program order adds to the 1152 cycles of MFMA time per slice instead of hiding under it (measured: the loop skeleton
-  // alone, with the MFMAs and every memory instruction taken out, cost 1040 cycles per slice).  So the state of
-  // iteration g + 1 is prepared in the middle of iteration g's second k-step.
-  struct Step {
-    int s, ti;
-    bool first, do_issue, do_masks, vm_all;
-    char* dma_dst;
-    const char* dma_src;  // doc rows or query rows of slice g + 3, by the wave's half
-    int nvalid;
-    uint32_t a1, b1, a0, b0;
-  };
-  int lp_s = -1, lp_ti = 0;
-  auto prep = [&](int g) __attribute__((always_inline)) -> Step {
-    Step t;
-    if (++lp_s == nslices) { lp_s = 0; ++lp_ti; }
-    t.s = lp_s;
-    t.ti = lp_ti;
-    t.first = lp_s == 0;
-    t.do_issue = g + 3 < total;
-    t.do_masks = masked && t.first && g > 0;  // (tile 0's mask rows are issued in the prologue)
-    t.vm_all = g + 2 >= total;
-    t.dma_dst = nullptr;
-    t.dma_src = nullptr;
-    if (t.do_issue) {
-      if (is_s == 0) issue_tile_setup();
-      t.dma_dst = lds + ((g + 3) % NST) * STAGE + ((fetch_docs ? 0 : NAI) + hw) * 1024;
-      t.dma_src = (fetch_docs ? is_dbase : is_qbase) + is_s * 64;
-      if (++is_s == nslices) { is_s = 0; ++is_ti; }
+  // the slice stream: (tile, slice) of the next slice to ISSUE and the tensor offset of its tile's doc / query block
+  int is_ti = 0, is_s = 0;
+  uint32_t is_base = 0;
+  auto issue_setup = [&]() __attribute__((always_inline)) {  // before the first instruction of a slice
+    if (is_s == 0) {
+      const int u = l + is_ti * nl;
+      is_base = (uint32_t)(first_half ? tile_doc(u) * a.Ld : tile_q0(u) * a.Lq) * rowb;
     }
-    t.nvalid = is_nvalid;
-    // fragment addresses: (g, k-step 1) for set 1, (g + 1, k-step 0) for set 0 (past the last slice: a stale stage, dropped)
-    const uint32_t st1 = (uint32_t)((g % NST) * STAGE), st0 = (uint32_t)(((g + 1) % NST) * STAGE);
-    const uint32_t pos1 = (uint32_t)(((2 + hh) ^ swz) * 16), pos0 = (uint32_t)((hh ^ swz) * 16);
-    t.a1 = st1 + ((wm * RW) * 32 + r) * 64 + pos1;
-    t.b1 = st1 + (TM + (wn * QB) * 32 + r) * 64 + pos1;
-    t.a0 = st0 + ((wm * RW) * 32 + r) * 64 + pos0;
-    t.b0 = st0 + (TM + (wn * QB) * 32 + r) * 64 + pos0;
-    return t;
   };
-  Step cur = prep(0);
-#ifdef MAXSIM_DIAG
-  uint64_t tS[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-  for (int g = 0; g < total; ++g) {
-    const int s = cur.s, ti = cur.ti;
-    // slice g + 1 has landed: this wave's part (counted: the instructions of slice g + 2 may still be in flight.  Loads retire
-    // in order, so "at most one slice's worth outstanding" implies slice g + 1 is in whatever the epilogue's younger stores and the
-    // mask rows are doing: at worst the wait runs a few instructions into slice g + 2), then everybody's.  The barrier also
-    // says: every wave is done reading slice g - 1, whose stage slice g + 3 overwrites.
-    AP_STAMP_TOP();
-    if (cur.vm_all) wait_vmcnt<0>(); else if (fetch_docs) wait_vmcnt<NDA>(); else wait_vmcnt<NDB>();
-    AP_STAMP(1);
-    wg_barrier();
-    AP_STAMP(2);
-    // One slice = two k-steps of R QB MFMAs, with the R + QB fragment reads of the next k-step and the LDS-DMA
-    // instructions of slice g + 3 between them.
-    constexpr int NM = RW * QB, NF = RW + QB;
-    constexpr int SLOTS = NM > NF ? NM - NF : 1;  // MFMAs of a k-step that have no fragment read behind them
-    constexpr int PER_A = (NDA + SLOTS - 1) / SLOTS, PER_B = (NDB + SLOTS - 1) / SLOTS;  // LDS-DMA instructions per such MFMA
-    // The two waves of a SIMD (w and w + HW) issue their LDS-DMA instructions in DIFFERENT k-steps -- the doc-row waves in
-    // k-step 0, the query-row waves in k-step 1: an LDS-DMA instruction holds the issuing wave for 100-180 cycles (stamped:
-    // a k-step with 4-5 of them took 780-1080 cycles, one without 200-260), and with both partners stalled at the same
-    // point of the slice nobody fed the matrix pipe meanwhile.  The doc rows are 2/3 of a slice: k-step 1 also carries
-    // the next iteration's bookkeeping.
-    const bool do_issue0 = cur.do_issue && fetch_docs, do_issue1 = cur.do_issue && !fetch_docs;
-    const bool first = cur.first;
-    char* const dma_dst = cur.dma_dst;
-    const char* const dma_src = cur.dma_src;
-#define AP_DMA_A(j)                                                                                                   \
-  do {                                                                                                                \
-    if (!AP_ABLATE_DMA) __builtin_amdgcn_global_load_lds(GPTR(dma_src + off[j]), LPTR(dma_dst + (j) * (HW * 1024)), 16, 0, 0); \
-  } while (0)
-#define AP_DMA_B(j)                                                                                                   \
+  auto issue_done = [&]() __attribute__((always_inline)) {
+    if (++is_s == nslices) { is_s = 0; ++is_ti; }
+  };
+  // instruction j of this wave's part of the slice (is_ti, is_s) into ring stage st
+#define AP_DMA(st, j)                                                                                                 \
   do {                                                                                                                \
     if (!AP_ABLATE_DMA)                                                                                               \
-      __builtin_amdgcn_global_load_lds(GPTR(dma_src + (((hw + HW * (j)) >> 1) < is_nvalid_cur ? off[j] : off[NDB + (j)])), LPTR(dma_dst + (j) * (HW * 1024)), 16, 0, 0); \
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (__attribute__((address_space(3))) void*)(lds3 + (st) * STAGE + dst_off + (j) * 4096), 16, \
+                                               (int)(lane_off + (is_base + (uint32_t)is_s * 128u + (uint32_t)(j) * j_stride)), 0, 0, 0); \
   } while (0)
+
+  // ---- compute side.  A fragment of row block b, k-step ks: row 32 b + r, chunk 2 ks + hh at position chunk ^ ((row >> 1) & 7)
+  //      = (hh ^ swz) ^ 2 ks: the k-step is an XOR of bits 5-6 of the byte address
+  const uint32_t swz = (uint32_t)((r >> 1) & 7);
+  const uint32_t fa0 = (uint32_t)(((wm * R) * 32 + r) * 128) + ((hh ^ swz) << 4);
+  const uint32_t fb0 = (uint32_t)((TM + (wn * QB) * 32 + r) * 128) + ((hh ^ swz) << 4);
+  f32x16 acc[R][QB];
+#pragma unroll
+  for (int b = 0; b < R; ++b)
+#pragma unroll
+    for (int q = 0; q < QB; ++q) acc[b][q] = (f32x16)(0.0f);
+  u32x4 fa[2][R], fb[2][QB];  // fragment sets, double-buffered by k-step
+  // ds_read_b128 by hand: the compiler does not know what an LDS-DMA instruction writes and orders its own LDS reads
+  // against them with s_waitcnt vmcnt(0); and it would wait for a set with lgkmcnt(0) right where it issues the next
+#define AP_READ(set, i, aa, ab)                                                                                       \
+  do {                                                                                                                \
+    if ((i) < R) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[set][(i) < R ? (i) : 0]) : "v"(aa), "n"(((i) < R ? (i) : 0) * 4096)); \
+    else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[set][(i) >= R && (i) < NF ? (i) - R : 0]) : "v"(ab), "n"(((i) >= R && (i) < NF ? (i) - R : 0) * 4096)); \
+  } while (0)
+  auto wait_frags = [&](int set) __attribute__((always_inline)) {  // every LDS read issued so far has returned
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int b = 0; b < R; ++b) asm volatile("" : "+v"(fa[set][b]));  // (the MFMAs below depend on this point)
+#pragma unroll
+    for (int q = 0; q < QB; ++q) asm volatile("" : "+v"(fb[set][q]));
+  };
 #define AP_MFMA(set, i, c0)                                                                                           \
   do {                                                                                                                \
     if (AP_ABLATE_MFMA) break;                                                                                        \
-    const int q_ = (i) / RW, b_ = (i) % RW;                                                                            \
+    const int q_ = (i) / R, b_ = (i) % R;                                                                             \
     const f32x16 c_ = (c0) ? (f32x16)(0.0f) : acc[b_][q_];                                                            \
     if constexpr (DT == MAXSIM_F16)                                                                                   \
       acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][b_]), __builtin_bit_cast(f16x8, fb[set][q_]), c_, 0, 0, 0); \
     else                                                                                                              \
       acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[set][b_]), __builtin_bit_cast(bf16x8, fb[set][q_]), c_, 0, 0, 0); \
   } while (0)
-    const int is_nvalid_cur = cur.nvalid;
-    const uint32_t a1 = cur.a1, b1 = cur.b1, a0 = cur.a0, b0 = cur.b0;
-    wait_frags(0);  // set 0 (requested during the previous k-step) is in: no younger LDS read is outstanding here
-    if (cur.do_masks) issue_masks(ti);
-    AP_STAMP(3);
-    // ---- k-step 0: MFMAs on set 0, between them the reads of set 1, then the LDS-DMA instructions of slice g + 3
-    //      (two copies, so that "a tile's first k-step starts from C = 0" is ONE branch per slice, not one per MFMA)
-#define AP_KSTEP0(C0)                                                                                                 \
-  _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                                    \
-    AP_MFMA(0, i, C0);                                                                                                \
-    if (i < RW) {                                                                                                     \
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < RW ? i : 0]) : "v"(a1), "n"(i * 2048));           \
-    } else if (i < NF) {                                                                                              \
-      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= RW && i < NF ? i - RW : 0]) : "v"(b1), "n"((i - RW) * 2048)); \
-    } else if (do_issue0) {                                                                                           \
-      _Pragma("unroll") for (int t = 0; t < PER_A; ++t) {                                                             \
-        const int j = (i - NF) * PER_A + t;                                                                           \
-        if (j < NDA) AP_DMA_A(j < NDA ? j : 0);                                                                       \
+
+  // ---- prologue: tile 0's mask rows and slice 0 on their way
+  if (total > 0) {
+    if (masked) issue_masks(0);
+    issue_setup();
+    if (first_half) {
+#pragma unroll
+      for (int j = 0; j < NDA; ++j) AP_DMA(0, j);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NDB; ++j) AP_DMA(0, j);
+    }
+    issue_done();
+  }
+
+  // ---- the loop: one slice = one barrier + four k-steps of R QB MFMAs.  Between the MFMAs of a k-step: the R + QB fragment
+  //      reads of the next k-step (none in the last: the next slice is only known to have landed after the barrier), then
+  //      this wave's LDS-DMA instructions of the NEXT slice -- into the other stage, which everybody finished reading
+  //      before the barrier -- in the k-steps of its half.
+  int cs = 0, cti = 0;  // (slice in tile, tile) being computed
+  for (int g = 0; g < total; ++g) {
+    const int st = g & 1;
+    // slice g has landed: this wave's part (everything it has in flight: the slice, a new tile's mask rows, the previous
+    // tile's result stores), then everybody's.  The barrier also says: every wave is done reading slice g - 1.
+    wait_vmcnt<0>();
+    wg_barrier();
+    const bool first = cs == 0;
+    const bool do_issue = g + 1 < total;
+    if (do_issue) issue_setup();
+    if (masked && first && g > 0) issue_masks(cti);  // (tile 0's mask rows are issued in the prologue)
+    const uint32_t aa = fa0 + (uint32_t)(st * STAGE), ab = fb0 + (uint32_t)(st * STAGE);
+#pragma unroll
+    for (int i = 0; i < NF; ++i) AP_READ(0, i, aa, ab);
+    // DMA instructions of this wave placed behind MFMA i of k-step ks (slots NF .. NM - 1 of a k-step carry no read)
+    constexpr int SLOTS = NM > NF ? NM - NF : 1;
+    constexpr int PER_A = (NDA / 2 + SLOTS - 1) / SLOTS, PER_B = (NDB + SLOTS - 1) / SLOTS;
+#define AP_KSTEP(ks, C0)                                                                                              \
+  {                                                                                                                   \
+    wait_frags((ks) & 1);                                                                                             \
+    const uint32_t an_ = aa ^ (((ks) + 1) << 5), bn_ = ab ^ (((ks) + 1) << 5);                                        \
+    _Pragma("unroll") for (int i = 0; i < NM; ++i) {                                                                  \
+      AP_MFMA((ks) & 1, i, C0);                                                                                       \
+      if ((ks) + 1 < KS && i < NF) AP_READ(((ks) + 1) & 1, i, an_, bn_);                                              \
+      if (i >= (NM > NF ? NF : NM - 1) && do_issue) {                                                                 \
+        const int sl_ = NM > NF ? i - NF : 0;                                                                         \
+        if (first_half && ((ks) == AP_DMA_A0 || (ks) == AP_DMA_A0 + 1)) {                                             \
+          _Pragma("unroll") for (int t = 0; t < (NM > NF ? PER_A : NDA / 2); ++t) {                                   \
+            const int j = ((ks) - AP_DMA_A0) * (NDA / 2) + sl_ * PER_A + t;                                           \
+            if (sl_ * PER_A + t < NDA / 2) AP_DMA(st ^ 1, j < NDA ? j : 0);                                           \
+          }                                                                                                           \
+        }                                                                                                             \
+        if (!first_half && (ks) == AP_DMA_B0) {                                                                       \
+          _Pragma("unroll") for (int t = 0; t < (NM > NF ? PER_B : NDB); ++t) {                                       \
+            const int j = sl_ * PER_B + t;                                                                            \
+            if (j < NDB) AP_DMA(st ^ 1, j < NDB ? j : 0);                                                             \
+          }                                                                                                           \
+        }                                                                                                             \
       }                                                                                                               \
     }                                                                                                                 \
+    if ((ks) + 1 < KS) { _Pragma("unroll") for (int i = NM; i < NF; ++i) AP_READ(((ks) + 1) & 1, i, an_, bn_); }      \
   }
-    if (first) { AP_KSTEP0(true) } else { AP_KSTEP0(false) }
-#undef AP_KSTEP0
-    // (what did not fit between the MFMAs: R QB < R + QB happens for R = 1)
-#pragma unroll
-    for (int i = NM; i < NF; ++i) {
-      if (i < RW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[1][i < RW ? i : 0]) : "v"(a1), "n"(i * 2048));
-      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[1][i >= RW && i < NF ? i - RW : 0]) : "v"(b1), "n"((i - RW) * 2048));
-    }
-    if (NM <= NF && do_issue0) {
-#pragma unroll
-      for (int j = 0; j < NDA; ++j) AP_DMA_A(j);
-    }
-    AP_STAMP(4);
-    wait_frags(1);
-    AP_STAMP(5);
-    // ---- k-step 1: MFMAs on set 1, between them the reads of the next slice's set 0
-    Step nxt = cur;
-#pragma unroll
-    for (int i = 0; i < NM; ++i) {
-      AP_MFMA(1, i, false);
-      if (i < RW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < RW ? i : 0]) : "v"(a0), "n"(i * 2048));
-      else if (i < NF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= RW && i < NF ? i - RW : 0]) : "v"(b0), "n"((i - RW) * 2048));
-      else if (do_issue1) {
-#pragma unroll
-        for (int t = 0; t < PER_B; ++t) {
-          const int j = (i - NF) * PER_B + t;
-          if (j < NDB) AP_DMA_B(j < NDB ? j : 0);
-        }
-      }
-      if (i == (NM > 2 ? 2 : NM - 1)) nxt = prep(g + 1);  // the next iteration's bookkeeping, under this k-step's MFMAs
-    }
-#pragma unroll
-    for (int i = NM; i < NF; ++i) {
-      if (i < RW) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fa[0][i < RW ? i : 0]) : "v"(a0), "n"(i * 2048));
-      else asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fb[0][i >= RW && i < NF ? i - RW : 0]) : "v"(b0), "n"((i - RW) * 2048));
-    }
-    if (NM <= NF && do_issue1) {
-#pragma unroll
-      for (int j = 0; j < NDB; ++j) AP_DMA_B(j);
-    }
-#undef AP_DMA_A
-#undef AP_DMA_B
-#undef AP_MFMA
-    AP_STAMP(6);
-    if (s + 1 < nslices) {
-      cur = nxt;
-      continue;
-    }
+    // (ONE copy of every k-step: the fragment reads are asynchronous behind the compiler's back -- where two branches
+    //  that both issue them meet, it may unify their destination registers with copies, i.e. read them before the data
+    //  is there.  A tile starts from accumulators zeroed at the end of the previous tile's epilogue instead of from a
+    //  C = 0 copy of its first k-step.)
+    AP_KSTEP(0, false)
+    AP_KSTEP(1, false)
+    AP_KSTEP(2, false)
+    AP_KSTEP(3, false)
+#undef AP_KSTEP
+    if (do_issue) issue_done();
+    if (++cs < nslices) continue;
 
-    // ---- epilogue of tile ti: similarities complete ----------------------------------------------------------------
-    const int u = l + ti * nl;
+    // ---- epilogue of tile cti: similarities complete ---------------------------------------------------------------
+    const int u = l + cti * nl;
     const int d = tile_doc(u), q0 = tile_q0(u);
+    const float* const dm = dm_lds;
+    const float* const qmp = qm_lds;
     // What the d_mask words of this wave's 32-row blocks are, block by block (wave-uniform): all 1 (a token row of the
     // doc: nothing to multiply), all 0 (padding inside Ld: every similarity is 0, the block's first row is its only
     // candidate), all NaN (tile padding past Ld: no candidate), or mixed.  With the reference's prefix masks
     // (tokenizers.py:57) at most one block of a doc is mixed.
     enum { BLK_MIXED = 0, BLK_ONES = 1, BLK_ZEROS = 2, BLK_NONE = 3 };
-    int kind[RW];
+    int kind[R];
 #pragma unroll
-    for (int b = 0; b < RW; ++b) {
-      const float w = dm_lds[(wm * RW + b) * 32 + r];
+    for (int b = 0; b < R; ++b) {
+      const float w = dm[(wm * R + b) * 32 + r];
       const bool ones = __builtin_amdgcn_ballot_w64(w == 1.0f) == ~0ull, zeros = __builtin_amdgcn_ballot_w64(w == 0.0f) == ~0ull;
       const bool nans = __builtin_amdgcn_ballot_w64(w != w) == ~0ull;
       kind[b] = ones ? BLK_ONES : zeros ? BLK_ZEROS : nans ? BLK_NONE : BLK_MIXED;
@@ -454,7 +316,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     for (int q = 0; q < QB; ++q) {  // one query at a time: the accumulators leave few registers for anything else
       const int qq = q0 + wn * QB + q;
       // tokens past Lq and query slots past nq: weight 0 (similarity 0, nothing written)
-      const float qm = (qq < a.nq && r < a.Lq) ? qm_lds[(wn * QB + q) * 32 + r] : 0.0f;
+      const float qm = (qq < a.nq && r < a.Lq) ? qmp[(wn * QB + q) * 32 + r] : 0.0f;
       // q_mask >= 0 (the reference's masks are 0/1: tokenizers.py:36,57) commutes with the max: max_n(qm x_n) = qm max_n(x_n),
       // one multiplication per token instead of one per similarity.  A negative weight anywhere in the wave (never built
       // by the reference, allowed by its interface) takes the multiplication back into the mask words of every block.
@@ -471,19 +333,18 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     if (AM) bidx = better ? (pos_) : bidx;                                                                            \
   } while (0)
 #define AP_SCAN(PREMUL)                                                                                               \
-  _Pragma("unroll") for (int b = 0; b < RW; ++b) {                                                                    \
+  _Pragma("unroll") for (int b = 0; b < R; ++b) {                                                                     \
     if (!PREMUL && kind[b] == BLK_ONES) {                                                                             \
       _Pragma("unroll") for (int v = 0; v < 16; ++v) AP_PICK(acc[b][q][v], b * 16 + v);                               \
     } else if (!PREMUL && kind[b] == BLK_ZEROS) {                                                                     \
       AP_PICK(0.0f, b * 16);                                                                                          \
     } else if (kind[b] != BLK_NONE) {                                                                                 \
-      int rowbase = (wm * RW + b) * 32 + 4 * hh;                                                                      \
+      int rowbase = (wm * R + b) * 32 + 4 * hh;                                                                       \
       /* opaque: otherwise the mask words are shared by the QB unrolled query iterations and stay live across them */ \
       asm volatile("" : "+v"(rowbase));                                                                               \
-      /* d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait (a read + wait per pair  */ \
-      /* of rows made the epilogue cost as much as the whole K loop: 14 us per tile); NaN past Ld (tile padding) */    \
+      /* d_mask of this lane's 16 rows of the block: four 16-byte reads up front, ONE wait; NaN past Ld */            \
       f32x4 d4[4];                                                                                                    \
-      _Pragma("unroll") for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm_lds + rowbase + 8 * k);                \
+      _Pragma("unroll") for (int k = 0; k < 4; ++k) d4[k] = *(const f32x4*)(dm + rowbase + 8 * k);                    \
       _Pragma("unroll") for (int v = 0; v < 16; v += 2) { /* rows in increasing order, two at a time (v_pk_mul_f32) */ \
         f32x2 w = {d4[v >> 2][v & 3], d4[v >> 2][(v & 3) + 1]};                                                       \
         if (PREMUL) w *= qm;                                                                                          \
@@ -501,7 +362,7 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       // (Q q_mask) . (D d_mask), BaseModel.py:41-43.  q_mask = 0 makes every similarity of the token 0: the first row wins
       const bool qzero = !premul && qm == 0.0f;
       if (!premul) best = qzero ? 0.0f : best * qm;
-      if (AM) bidx = qzero ? (wm == 0 && hh == 0 ? 0 : 0x7fffffff) : (wm * RW + (bidx >> 4)) * 32 + 4 * hh + (bidx & 3) + 8 * ((bidx & 15) >> 2);
+      if (AM) bidx = qzero ? (wm == 0 && hh == 0 ? 0 : 0x7fffffff) : (wm * R + (bidx >> 4)) * 32 + 4 * hh + (bidx & 3) + 8 * ((bidx & 15) >> 2);
       // the two lane halves hold interleaved rows of the same query token
       const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(best), __float_as_uint(best), false, false);
       const float va = __uint_as_float(sv[0]), vb = __uint_as_float(sv[1]);
@@ -517,23 +378,22 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
         v2 = fmaxf(va, vb);
       }
       if (lane < 32) {
-        ex_v[((wn * QB + q) * WM + wm) * 32 + lane] = v2;
-        if (AM) ex_i[((wn * QB + q) * WM + wm) * 32 + lane] = i2;
+        ex_v[((wn * QB + q) * 4 + wm) * 32 + lane] = v2;
+        if (AM) ex_i[((wn * QB + q) * 4 + wm) * 32 + lane] = i2;
       }
     }
     lds_barrier();
-    // the row-waves' results meet: wave w finishes query slots w, w + WV, ... of the tile
-#pragma unroll
-    for (int qs = wave; qs < NQ; qs += WV) {
-      const int qq = q0 + qs;
+    // the row-waves' results meet: wave w finishes query slot w of the tile (NQ <= 8 slots)
+    if (wave < NQ) {
+      const int qq = q0 + wave;
       float best = NEG_INF;
       int bidx = 0;
 #pragma unroll
-      for (int w = 0; w < WM; ++w) {  // increasing row ranges: strict > keeps the first maximal token
-        const float v = ex_v[(qs * WM + w) * 32 + r];
+      for (int w = 0; w < 4; ++w) {  // increasing row ranges: strict > keeps the first maximal token
+        const float v = ex_v[(wave * 4 + w) * 32 + r];
         const bool better = v > best;
         best = better ? v : best;
-        if (AM) bidx = better ? ex_i[(qs * WM + w) * 32 + r] : bidx;
+        if (AM) bidx = better ? ex_i[(wave * 4 + w) * 32 + r] : bidx;
       }
       if (qq < a.nq) {
         if (AM && lane < a.Lq) a.argmax[((int64_t)qq * a.nd + d) * a.Lq + lane] = bidx;
@@ -547,16 +407,17 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
         if (lane == 0) a.scores[(int64_t)qq * a.nd + d] = sc;
       }
     }
-    // (the exchange area is rewritten only after the next tile's slices, i.e. after many more barriers)
-    AP_STAMP(7);
-    cur = nxt;
+    // (the exchange area and the mask rows are rewritten only after the next barrier)
+#pragma unroll
+    for (int b = 0; b < R; ++b)
+#pragma unroll
+      for (int q = 0; q < QB; ++q) acc[b][q] = (f32x16)(0.0f);
+    cs = 0;
+    ++cti;
   }
-#ifdef MAXSIM_DIAG
-  if ((int)blockIdx.x == a.stamp_wg) {
-    __syncthreads();
-    for (int i = tid; i < 2 * 24 * 9; i += WV * 64) g_ap_stamps[i] = st_lds[i];
-  }
-#endif
+#undef AP_DMA
+#undef AP_READ
+#undef AP_MFMA
 }
 
 }  // namespace maxsim

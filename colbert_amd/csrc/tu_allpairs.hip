@@ -20,11 +20,8 @@ int cu_count() {  // workgroups are persistent, one per CU; the XCD-aware tile w
 
 template <int DT, int R, int QB, bool AM>
 int launch_r(const AllPairsArgs& a, hipStream_t st) {
-#ifdef MAXSIM_DIAG
-  constexpr int ldsb = 4 * (128 * R + 64 * QB) * 64 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4 + 2 * 24 * 9 * 8;
-#else
-  constexpr int ldsb = 4 * (128 * R + 64 * QB) * 64 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4;
-#endif
+  // 2 ring stages of 64 dims + the row-waves' (max, index) exchange + the tile's mask rows
+  constexpr int ldsb = 2 * (128 * R + 64 * QB) * 128 + 2 * (2 * QB * 4 * 32) * 4 + (128 * R + 64 * QB) * 4;
   auto kern = k_maxsim_allpairs<DT, R, QB, AM>;
   int rc = allow_lds(kern, ldsb);
   if (rc) return rc;
@@ -41,13 +38,16 @@ int launch_dt(const AllPairsArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// MAXSIM_ERANGE: not a shape this kernel serves (16-bit operands, h % 32 == 0, Lq <= 32, Ld <= 384, enough work to fill
+// MAXSIM_ERANGE: not a shape this kernel serves (16-bit operands, h % 64 == 0, h >= 128, Lq <= 32, Ld <= 384, enough work to fill
 // the chip with (doc, 8-query) tiles) -- the caller takes the streaming kernel.
 int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st) {
   if (dt != MAXSIM_F16 && dt != MAXSIM_BF16) return MAXSIM_ERANGE;
   if (p.q_dtype != dt) return MAXSIM_ERANGE;
-  if (p.h < 32 || (p.h & 31) || p.Lq < 1 || p.Lq > 32 || p.Ld < 1 || p.Ld > 384) return MAXSIM_ERANGE;
+  if (p.h < 128 || (p.h & 63) || p.Lq < 1 || p.Lq > 32 || p.Ld < 1 || p.Ld > 384) return MAXSIM_ERANGE;
   if ((((uintptr_t)p.Q | (uintptr_t)p.index) & 15) != 0) return MAXSIM_ERANGE;
+  // the kernel addresses Q and D with 32-bit offsets from the tensor base (buffer descriptors: reads past the end give 0)
+  const uint64_t lim = 0xF0000000ull, rowb = (uint64_t)p.h * 2;
+  if ((uint64_t)p.ncand * p.Ld * rowb >= lim || (uint64_t)p.nq * p.Lq * rowb >= lim) return MAXSIM_ERANGE;
   // masks travel by LDS-DMA as float words (see the kernel): float32 masks or none; colbert_amd.score converts
   if (p.mask_dtype != MAXSIM_MASK_NONE && p.mask_dtype != MAXSIM_MASK_F32) return MAXSIM_ERANGE;
   const int64_t tiles = (int64_t)p.ncand * ((p.nq + 7) / 8);  // (doc, query block) tiles, roughly
@@ -56,19 +56,9 @@ int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st) {
   AllPairsArgs a{};
   a.Q = p.Q; a.D = p.index; a.q_mask = p.q_mask; a.d_mask = p.d_mask;
   a.scores = p.scores; a.argmax = p.argmax;
-#ifdef MAXSIM_DIAG
-  a.stamp_g0 = MAXSIM_KNOB("MAXSIM_AP_STAMP_G0", 48);
-  a.stamp_wg = MAXSIM_KNOB("MAXSIM_AP_STAMP_WG", -1);
-#endif
   a.mask_dtype = p.mask_dtype; a.nq = p.nq; a.nd = p.ncand; a.Lq = p.Lq; a.Ld = p.Ld; a.h = p.h;
   if (dt == MAXSIM_F16) return argmax ? launch_dt<MAXSIM_F16, true>(a, st) : launch_dt<MAXSIM_F16, false>(a, st);
   return argmax ? launch_dt<MAXSIM_BF16, true>(a, st) : launch_dt<MAXSIM_BF16, false>(a, st);
 }
 
 }  // namespace maxsim
-
-#ifdef MAXSIM_DIAG
-extern "C" int maxsim_diag_allpairs_stamps(uint64_t* out) {  // host copy of the last stamped launch (diagnostic build)
-  return hipMemcpyFromSymbol(out, HIP_SYMBOL(maxsim::g_ap_stamps), sizeof(maxsim::g_ap_stamps)) == hipSuccess ? 0 : -1;
-}
-#endif

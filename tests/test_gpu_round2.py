@@ -394,8 +394,8 @@ def test_topk_selection_with_heavy_ties(ca, ncand, k):
 @pytest.mark.parametrize("cfg", [
     dict(nq=50, nd=70, Lq=32, Ld=384, h=768, dtype=torch.bfloat16),     # the reference's training shape, R = 3
     dict(nq=23, nd=41, Lq=32, Ld=256, h=128, dtype=torch.float16),      # R = 2 exactly full
-    dict(nq=16, nd=90, Lq=9, Ld=129, h=64, dtype=torch.bfloat16),       # R = 2, one row past 128
-    dict(nq=31, nd=33, Lq=32, Ld=128, h=32, dtype=torch.float16),       # R = 1, one K slice
+    dict(nq=16, nd=90, Lq=9, Ld=129, h=128, dtype=torch.bfloat16),      # R = 2, one row past 128; two K slices (the least)
+    dict(nq=31, nd=33, Lq=32, Ld=128, h=192, dtype=torch.float16),      # R = 1, three K slices
     dict(nq=8, nd=200, Lq=32, Ld=1, h=256, dtype=torch.bfloat16),       # one-token docs
 ])
 def test_allpairs_kernel_matches_streaming_kernel_and_oracle(ca, cfg):
@@ -455,7 +455,7 @@ def test_allpairs_kernel_prefix_masks(ca, Ld, dt):
     from colbert_amd.scoring import _DT, _MDT
     L = ca._lib.lib
     gen = torch.Generator().manual_seed(5 + Ld)
-    nq, nd, Lq, h = 20, 72, 32, 64
+    nq, nd, Lq, h = 20, 72, 32, 128
     Q = nrm(gen, nq, Lq, h).to(dt)
     D = nrm(gen, nd, Ld, h).to(dt)
     lens = torch.randint(1, Ld + 1, (nd,), generator=gen)
