@@ -17,7 +17,7 @@ OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk",
            "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
            "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_rank_forward_workspace_bytes", "maxsim_doc_table_bytes",
-           "maxsim_build_doc_table", "maxsim_shard_candidates")
+           "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel")
 
 
 class IndexView(ctypes.Structure):
@@ -70,6 +70,8 @@ def _load():
     lib.maxsim_doc_table_bytes.argtypes = [i64]
     lib.maxsim_build_doc_table.restype = i32
     lib.maxsim_build_doc_table.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.maxsim_score_dense_kernel.restype = i32
+    lib.maxsim_score_dense_kernel.argtypes = [i32] * 7
     lib.maxsim_shard_candidates.restype = i32
     lib.maxsim_shard_candidates.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32

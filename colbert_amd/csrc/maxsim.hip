@@ -115,6 +115,11 @@ static int score_dense_impl(const void* Q, const void* D, const void* q_mask, co
   return launch_generic<MODE_DENSE>(p, dtype, st);
 }
 
+int maxsim_score_dense_kernel(int nq, int nd, int Lq, int Ld, int h, int dtype, int mask_dtype) {
+  if (nq < 0 || nd < 0 || Lq < 1 || Ld < 1 || h < 1 || dtype < MAXSIM_F32 || dtype > MAXSIM_BF16) return MAXSIM_EINVAL;
+  return allpairs_serves(dtype, dtype, mask_dtype, nq, nd, Lq, Ld, h) ? 1 : 0;
+}
+
 int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
                        int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, void* stream) {
   return score_dense_impl(Q, D, q_mask, d_mask, nq, nd, Lq, Ld, h, dtype, mask_dtype, out, nullptr, stream);

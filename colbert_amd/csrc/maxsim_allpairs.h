@@ -83,7 +83,7 @@ __device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are d
 #define AP_DMA_A0 0
 #endif
 #ifndef AP_DMA_B0
-#define AP_DMA_B0 2
+#define AP_DMA_B0 1
 #endif
 
 template <int DT, int R, int QB, bool AM>

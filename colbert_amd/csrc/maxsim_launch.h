@@ -92,5 +92,6 @@ int launch_bigh_rerank(Params& p, int dt, hipStream_t st);
 int launch_bigh_dense(Params& p, int dt, bool argmax, hipStream_t st);
 // tu_allpairs.hip: the GEMM-blocked all-pairs kernel (16-bit operands, Lq <= 32, Ld <= 384); MAXSIM_ERANGE = not its shape.
 int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st);
+bool allpairs_serves(int dt, int q_dtype, int mask_dtype, int nq, int nd, int Lq, int Ld, int h);
 
 }  // namespace maxsim

@@ -38,21 +38,27 @@ int launch_dt(const AllPairsArgs& a, hipStream_t st) {
 
 }  // namespace
 
-// MAXSIM_ERANGE: not a shape this kernel serves (16-bit operands, h % 64 == 0, h >= 128, Lq <= 32, Ld <= 384, enough work to fill
-// the chip with (doc, 8-query) tiles) -- the caller takes the streaming kernel.
-int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st) {
-  if (dt != MAXSIM_F16 && dt != MAXSIM_BF16) return MAXSIM_ERANGE;
-  if (p.q_dtype != dt) return MAXSIM_ERANGE;
-  if (p.h < 128 || (p.h & 63) || p.Lq < 1 || p.Lq > 32 || p.Ld < 1 || p.Ld > 384) return MAXSIM_ERANGE;
-  if ((((uintptr_t)p.Q | (uintptr_t)p.index) & 15) != 0) return MAXSIM_ERANGE;
-  // the kernel addresses Q and D with 32-bit offsets from the tensor base (buffer descriptors: reads past the end give 0)
-  const uint64_t lim = 0xF0000000ull, rowb = (uint64_t)p.h * 2;
-  if ((uint64_t)p.ncand * p.Ld * rowb >= lim || (uint64_t)p.nq * p.Lq * rowb >= lim) return MAXSIM_ERANGE;
+// Does the GEMM-blocked kernel serve this shape (16-bit operands, h % 64 == 0, h >= 128, Lq <= 32, Ld <= 384, float32
+// masks or none, tensors below 3.75 GB, enough work to fill the chip with (doc, 8-query) tiles)?  Otherwise the caller
+// takes the streaming kernel.
+bool allpairs_serves(int dt, int q_dtype, int mask_dtype, int nq, int nd, int Lq, int Ld, int h) {
+  if (dt != MAXSIM_F16 && dt != MAXSIM_BF16) return false;
+  if (q_dtype != dt) return false;
+  if (h < 128 || (h & 63) || Lq < 1 || Lq > 32 || Ld < 1 || Ld > 384) return false;
   // masks travel by LDS-DMA as float words (see the kernel): float32 masks or none; colbert_amd.score converts
-  if (p.mask_dtype != MAXSIM_MASK_NONE && p.mask_dtype != MAXSIM_MASK_F32) return MAXSIM_ERANGE;
-  const int64_t tiles = (int64_t)p.ncand * ((p.nq + 7) / 8);  // (doc, query block) tiles, roughly
+  if (mask_dtype != MAXSIM_MASK_NONE && mask_dtype != MAXSIM_MASK_F32) return false;
+  // the kernel addresses Q and D with 32-bit offsets from the tensor base (buffer descriptors: reads past the end give 0)
+  const uint64_t lim = 0xF0000000ull, rowb = (uint64_t)h * 2;
+  if ((uint64_t)nd * Ld * rowb >= lim || (uint64_t)nq * Lq * rowb >= lim) return false;
+  const int64_t tiles = (int64_t)nd * ((nq + 7) / 8);  // (doc, query block) tiles, roughly
   const int min_tiles = MAXSIM_KNOB("MAXSIM_ALLPAIRS_MIN_TILES", 128);  // diagnostic builds: 0 = always, huge = never
-  if (tiles < min_tiles) return MAXSIM_ERANGE;
+  return tiles >= min_tiles;
+}
+
+// MAXSIM_ERANGE: not a shape (or an alignment) this kernel serves.
+int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st) {
+  if (!allpairs_serves(dt, p.q_dtype, p.mask_dtype, p.nq, p.ncand, p.Lq, p.Ld, p.h)) return MAXSIM_ERANGE;
+  if ((((uintptr_t)p.Q | (uintptr_t)p.index) & 15) != 0) return MAXSIM_ERANGE;
   AllPairsArgs a{};
   a.Q = p.Q; a.D = p.index; a.q_mask = p.q_mask; a.d_mask = p.d_mask;
   a.scores = p.scores; a.argmax = p.argmax;

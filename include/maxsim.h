@@ -39,8 +39,8 @@
 extern "C" {
 #endif
 
-#define MAXSIM_VERSION 110 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
-                              maxsim_shard_candidates, maxsim_build_doc_table */
+#define MAXSIM_VERSION 111 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
+                              maxsim_shard_candidates, maxsim_build_doc_table; 111: maxsim_score_dense_kernel */
 
 /* element types of Q / D / index */
 #define MAXSIM_F32 0
@@ -99,6 +99,12 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
  *   both are fully overwritten).  fp32 accumulation in a fixed order (reproducible) except in the global-atomics fallback.
  * h <= 1024 for the backward.
  */
+/* Which kernel serves an all-pairs problem of this shape with 16-byte aligned operands: 1 = the GEMM-blocked kernel
+ * (16-bit Q and D of one type, h % 64 == 0, h >= 128, Lq <= 32, Ld <= 384, float32 masks or none, Q and D below 3.75 GB
+ * each, at least 128 (doc, 8-query) tiles), 0 = the streaming / generic kernels (everything else).  Results are the
+ * same either way; tests and benchmarks use this to say what they measured.  Negative: MAXSIM_EINVAL. */
+int maxsim_score_dense_kernel(int nq, int nd, int Lq, int Ld, int h, int dtype, int mask_dtype);
+
 int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
                            int Lq, int Ld, int h, int dtype, int mask_dtype, float* out, int32_t* argmax,
                            void* stream);

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.lib.maxsim_version() == 110
+    assert lib.lib.maxsim_version() == 111
     assert lib.strerror(0) == "ok"
     for code in (-1, -2, -3, -4):
         assert lib.strerror(code) not in ("ok", "unknown error")
@@ -66,6 +66,14 @@ def test_validation_without_launch(lib):
     assert L.maxsim_doc_table_bytes(1000) == 16000 and L.maxsim_doc_table_bytes(0) == 0
     assert L.maxsim_build_doc_table(None, None, None, 0, None, None) == lib.OK
     assert L.maxsim_build_doc_table(None, None, None, 4, None, None) == lib.EINVAL
+    # which kernel serves an all-pairs shape (pure host logic): the training step takes the GEMM-blocked kernel
+    assert L.maxsim_score_dense_kernel(272, 544, 32, 384, 768, lib.BF16, lib.MASK_F32) == 1
+    assert L.maxsim_score_dense_kernel(272, 544, 32, 384, 768, lib.F32, lib.MASK_F32) == 0      # fp32 operands
+    assert L.maxsim_score_dense_kernel(272, 544, 32, 384, 96, lib.BF16, lib.MASK_F32) == 0       # h % 64
+    assert L.maxsim_score_dense_kernel(272, 544, 32, 385, 768, lib.BF16, lib.MASK_F32) == 0      # Ld > 384
+    assert L.maxsim_score_dense_kernel(272, 544, 32, 384, 768, lib.BF16, lib.MASK_I64) == 0      # integer masks
+    assert L.maxsim_score_dense_kernel(8, 64, 32, 384, 768, lib.BF16, lib.MASK_NONE) == 0        # too few tiles
+    assert L.maxsim_score_dense_kernel(8, 64, 0, 384, 768, lib.BF16, lib.MASK_NONE) == lib.EINVAL
     assert L.maxsim_shard_candidates(None, 0, 10, 0, 5, None, None, None, None) == lib.OK
     assert L.maxsim_shard_candidates(None, 2, 10, 5, 0, None, None, None, None) == lib.EINVAL
     assert L.maxsim_shard_candidates(None, 2, 10, 0, 5, None, None, None, None) == lib.EINVAL

@@ -393,7 +393,7 @@ def test_topk_selection_with_heavy_ties(ca, ncand, k):
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("cfg", [
     dict(nq=50, nd=70, Lq=32, Ld=384, h=768, dtype=torch.bfloat16),     # the reference's training shape, R = 3
-    dict(nq=23, nd=41, Lq=32, Ld=256, h=128, dtype=torch.float16),      # R = 2 exactly full
+    dict(nq=23, nd=45, Lq=32, Ld=256, h=128, dtype=torch.float16),      # R = 2 exactly full
     dict(nq=16, nd=90, Lq=9, Ld=129, h=128, dtype=torch.bfloat16),      # R = 2, one row past 128; two K slices (the least)
     dict(nq=31, nd=33, Lq=32, Ld=128, h=192, dtype=torch.float16),      # R = 1, three K slices
     dict(nq=8, nd=200, Lq=32, Ld=1, h=256, dtype=torch.bfloat16),       # one-token docs
@@ -414,6 +414,8 @@ def test_allpairs_kernel_matches_streaming_kernel_and_oracle(ca, cfg):
     dm = (torch.rand(nd, Ld, generator=gen) > 0.25).long()
     dm[:, 0] = 1
     Qd, Dd = Q.cuda(), D.cuda()
+    assert L.maxsim_score_dense_kernel(nq, nd, Lq, Ld, h, _DT[dt], _MDT[torch.float32]) == 1     # the GEMM-blocked kernel ...
+    assert L.maxsim_score_dense_kernel(nq, nd, Lq, Ld, h, _DT[dt], _MDT[torch.int64]) == 0       # ... and the streaming one
     res = {}
     for name, mt in (("gemm", torch.float32), ("stream", torch.int64)):
         qmd, dmd = qm.to(mt).cuda(), dm.to(mt).cuda()
@@ -465,6 +467,7 @@ def test_allpairs_kernel_prefix_masks(ca, Ld, dt):
     qlen = torch.randint(1, Lq + 1, (nq,), generator=gen)
     qm = (torch.arange(Lq)[None, :] < qlen[:, None]).long()
     Qd, Dd = Q.cuda(), D.cuda()
+    assert L.maxsim_score_dense_kernel(nq, nd, Lq, Ld, h, _DT[dt], _MDT[torch.float32]) == 1
     res = {}
     for name, mt in (("gemm", torch.float32), ("stream", torch.int64)):
         qmd, dmd = qm.to(mt).cuda(), dm.to(mt).cuda()
@@ -516,6 +519,7 @@ def test_allpairs_kernel_general_float_masks(ca, Ld):
     out = torch.empty(nq, nd, device="cuda")
     arg = torch.full((nq, nd, Lq), -7, dtype=torch.int32, device="cuda")
     Qd, Dd, qmd, dmd = Q.cuda(), D.cuda(), qm.cuda(), dm.cuda()
+    assert L.maxsim_score_dense_kernel(nq, nd, Lq, Ld, h, _DT[dt], _MDT[torch.float32]) == 1
     rc = L.maxsim_score_dense_fwd(Qd.data_ptr(), Dd.data_ptr(), qmd.data_ptr(), dmd.data_ptr(), nq, nd, Lq, Ld, h,
                                   _DT[dt], _MDT[torch.float32], out.data_ptr(), arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
     assert rc == 0
