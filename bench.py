@@ -366,6 +366,8 @@ def main():
             res["stratified"] = strat
         if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
             res["single_query"] = single_query_probe(ranker, Q, cands, H, LQ, esize)
+        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
+            res["training_form"] = training_form_probe(dev)
         if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
@@ -425,6 +427,46 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     out["batch16"] = {"kernel_ms": round(ks[len(ks) // 2], 4), "algorithmic_GBps": round(b16 / (ks[len(ks) // 2] * 1e-3) / 1e9, 1),
                       "how": "20 launches of 16 queries x 1000 candidates back to back, HIP events around the 20"}
     return out
+
+
+def training_form_probe(dev):
+    """The operator's second caller: BaseModel.score on the gathered training batch (colbert_model.py:87-90),
+    every query against every doc, at the reference's step -- Q 272 x 32 x 768, D 544 x 384 x 768 bf16 (dense.yaml:6-8) --
+    through maxsim_score_dense_fwd (scores + arg-max for the backward).  Matrix-bound, unlike the rerank path: priced
+    against the dense bf16 MFMA peak.  Not the headline metric; one line so that the number is in the bench record."""
+    import torch.nn.functional as F
+    from colbert_amd import _lib
+    from colbert_amd.scoring import _DT, _MDT
+    nq, nd, lq, ld, h = 272, 544, 32, 384, 768
+    g = torch.Generator(device=dev).manual_seed(3)
+    Qt = F.normalize(torch.randn(nq, lq, h, generator=g, device=dev), dim=-1).bfloat16()
+    Dt = F.normalize(torch.randn(nd, ld, h, generator=g, device=dev), dim=-1).bfloat16()
+    qm = torch.ones(nq, lq, dtype=torch.float32, device=dev)
+    dm = (torch.arange(ld, device=dev)[None, :] < torch.randint(ld // 4, ld + 1, (nd, 1), generator=g, device=dev)).float()
+    out = torch.empty(nq, nd, device=dev)
+    arg = torch.empty(nq, nd, lq, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def launch():
+        rc = _lib.lib.maxsim_score_dense_fwd(Qt.data_ptr(), Dt.data_ptr(), qm.data_ptr(), dm.data_ptr(), nq, nd, lq, ld, h,
+                                             _DT[torch.bfloat16], _MDT[torch.float32], out.data_ptr(), arg.data_ptr(), st)
+        assert rc == 0, rc
+    for _ in range(3):
+        launch()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        launch()
+    e1.record()
+    e1.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    flop = 2.0 * nq * nd * lq * ld * h
+    return {"op": "maxsim_score_dense_fwd (scores + arg-max), Q 272x32x768 x D 544x384x768, bf16, prefix d_mask",
+            "kernel": "k_maxsim_allpairs" if _lib.lib.maxsim_score_dense_kernel(nq, nd, lq, ld, h, _DT[torch.bfloat16], _MDT[torch.float32]) == 1 else "k_maxsim_stream_bigh",
+            "forward_ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1), "peak_tflops_dense_bf16": 2500.0,
+            "frac": round(flop / ms / 1e9 / 2500.0, 4), "how": f"{n} launches back to back between two HIP events",
+            "profile": "profiles/r02_allpairs_kernel_stats.csv, profiles/r02_allpairs_pmc.json"}
 
 
 if __name__ == "__main__":
