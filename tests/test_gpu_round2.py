@@ -499,6 +499,39 @@ def test_allpairs_kernel_prefix_masks(ca, Ld, dt):
 
 
 @pytest.mark.gpu
+def test_allpairs_kernel_addresses_past_2_gib(ca):
+    """The GEMM-blocked kernel addresses D with 32-bit byte offsets from the tensor base (a buffer descriptor): a D of
+    2.2 GiB puts the last docs past 2^31.  First, middle and last docs against float32 torch on the same rounded inputs;
+    the last doc also exercises the reads past the end of the tensor (its tile's padding rows)."""
+    from colbert_amd.scoring import _DT, _MDT
+    L = ca._lib.lib
+    nq, nd, Lq, Ld, h, dt = 8, 3900, 32, 380, 768, torch.bfloat16          # 3900 x 380 x 1536 B = 2.12 GiB
+    assert nd * Ld * h * 2 > 2 ** 31
+    g = torch.Generator(device="cuda").manual_seed(11)
+    Q = torch.nn.functional.normalize(torch.randn(nq, Lq, h, generator=g, device="cuda"), dim=-1).to(dt)
+    D = torch.empty(nd, Ld, h, dtype=dt, device="cuda")
+    for i in range(0, nd, 500):                                              # (float32 staging in pieces: 0.6 GB at a time)
+        D[i:i + 500] = torch.nn.functional.normalize(torch.randn(min(500, nd - i), Ld, h, generator=g, device="cuda"), dim=-1).to(dt)
+    assert L.maxsim_score_dense_kernel(nq, nd, Lq, Ld, h, _DT[dt], 0) == 1
+    out = torch.empty(nq, nd, device="cuda")
+    arg = torch.full((nq, nd, Lq), -7, dtype=torch.int32, device="cuda")
+    rc = L.maxsim_score_dense_fwd(Q.data_ptr(), D.data_ptr(), None, None, nq, nd, Lq, Ld, h, _DT[dt], 0,
+                                  out.data_ptr(), arg.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    docs = torch.tensor([0, 1, 7, 8, 1949, 2000, 3678, 3679, 3680, 3681, 3891, 3892, 3898, 3899], device="cuda")  # 3680: the first past 2^31
+    sim = torch.einsum("qmh,dnh->qdmn", Q.float(), D[docs].float())
+    exp = sim.max(-1).values.sum(-1)
+    torch.testing.assert_close(out[:, docs], exp, rtol=0, atol=ATOL16)
+    top2 = sim.topk(2, dim=-1).values
+    clear = top2[..., 0] - top2[..., 1] > 1e-4
+    got = arg[:, docs]
+    assert bool((got >= 0).all()) and bool((got < Ld).all())
+    assert bool((got[clear] == sim.argmax(-1).to(torch.int32)[clear]).all())
+    assert bool(torch.isfinite(out).all())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("Ld", [100, 200, 300])
 def test_allpairs_kernel_general_float_masks(ca, Ld):
     """Masks the reference never builds but its interface allows: fractional, negative and zero float32 weights on both
