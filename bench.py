@@ -382,13 +382,13 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     events recorded on the launch stream right before and after the call (both kernels + the gap between them);
     `host_ms` = end-to-end minus that span (the events themselves add a few us to the span: the kernel's own duration is
     in profiles/r02_single_query_*)."""
-    Q1 = Q[:1].float().permute(0, 2, 1).contiguous()           # [1, h, Lq] as ColbertRetriever.search hands it over
+    Q1 = Q[:1].float().permute(0, 2, 1)     # [1, h, Lq]: the permuted VIEW of a [1, Lq, h] tensor, as faiss_indexers.py:232-233 hands it over
     out = {"call": "rank_forward(Q[1,h,Lq], 1000 pids, depth=100) -> python lists"}
     lat, span = [], []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     import ctypes
     from colbert_amd import _lib
-    Qt = Q1.permute(0, 2, 1).contiguous()
+    Qt = Q1.permute(0, 2, 1).contiguous()   # (what rank_forward makes of it: the original layout, no copy)
     for it in range(160):
         pids1 = cands[it % cands.size(0), it % cands.size(1)].tolist()        # fresh docs every call: HBM, not cache
         if it % 2 == 0:

@@ -17,3 +17,8 @@ done
 for p in "${pids[@]}"; do wait "$p"; done
 "$HIPCC" --offload-arch=gfx950 -shared -fPIC "$OBJ"/maxsim.o "$OBJ"/tu_stream.o "$OBJ"/tu_stream_small.o "$OBJ"/tu_allpairs.o "$OBJ"/tu_bigh_rerank.o \
     "$OBJ"/tu_bigh_dense.o "$OBJ"/tu_bigh_dense_am.o -o "$OUT"
+# the CPython glue of the online call (host side, above the C ABI): only with the product library
+if [ -z "${MAXSIM_OUT:-}" ]; then
+  PYINC="$(python3 -c 'import sysconfig; print(sysconfig.get_paths()["include"])')"
+  gcc -O2 -shared -fPIC -Wall -I"$PYINC" "$HERE/fastrank.c" -o "$ROOT/colbert_amd/_fastrank.so"
+fi

@@ -21,6 +21,12 @@ from . import _lib, index_io
 from ._pinned import PinnedBuffer
 from .scoring import _DT, _ptr, _stream
 
+try:        # CPython glue of rank_forward's online path (csrc/fastrank.c, built next to libmaxsim.so); optional: without it
+    from . import _fastrank          # the same library call is made through ctypes
+except ImportError:
+    _fastrank = None
+_RANK_FORWARD_FN = ctypes.cast(_lib.lib.maxsim_rank_forward, ctypes.c_void_p).value
+
 BSIZE = 1 << 14  # colbert_ranker.py:11
 
 
@@ -276,7 +282,10 @@ class ColbertRanker:
         k = min(int(depth), n_pids)
         Qt = Q.permute(0, 2, 1)                                               # :111 -> [1, Lq, h]; a view of the caller's q
         qdt = Qt.dtype if Qt.dtype in (torch.float16, torch.bfloat16) else torch.float32
-        Qt = Qt.to(device=dev, dtype=qdt).contiguous()                        # :78 (a no-op for faiss_indexers.py:232-233)
+        if Qt.dtype != qdt or Qt.device != dev:                               # :78 (a no-op for faiss_indexers.py:232-233)
+            Qt = Qt.to(device=dev, dtype=qdt)
+        if not Qt.is_contiguous():
+            Qt = Qt.contiguous()
         assert Qt.size(2) == self.dim, (Qt.size(2), self.dim)
         if n_pids > BSIZE or output_D_embedding:
             pids_t = torch.tensor(pids) if type(pids) is list else pids
@@ -293,6 +302,20 @@ class ColbertRanker:
         ws = getattr(self._tls, "ws", None)
         if ws is None:
             ws = self._tls.ws = _Workspace(dev)
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        if type(pids) is list and _fastrank is not None and torch.cuda.current_device() == idx:
+            # list in, lists out, one C call in between (csrc/fastrank.c: the same library call as below, ~10 us less
+            # interpreter work around it); anything unusual in the list takes the general path
+            try:
+                r = _fastrank.rank_forward(_RANK_FORWARD_FN, ctypes.addressof(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1),
+                                           pids, k, ws.in_ptr, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr,
+                                           torch._C._cuda_getCurrentRawStream(idx))
+            except (TypeError, OverflowError):
+                r = None
+            if r is not None:
+                if type(r) is int:
+                    _lib.check(r, "maxsim_rank_forward")
+                return r
         if type(pids) is list:
             try:        # 1000 python ints: 8 us through array('q') against 50-75 us for torch.tensor(list)
                 a = array.array("q", pids)
@@ -306,7 +329,6 @@ class ColbertRanker:
         else:
             ws.pin_in[:n_pids] = pids.to(torch.int64).numpy()
             pid_ptr = ws.in_ptr
-        idx = dev.index if dev.index is not None else torch.cuda.current_device()
         switch = torch.cuda.current_device() != idx
         if switch:
             prev = torch.cuda.current_device()

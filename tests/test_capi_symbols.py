@@ -94,3 +94,42 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     mod = importlib.util.module_from_spec(spec)
     with pytest.raises(ImportError):
         spec.loader.exec_module(mod)
+
+
+def test_fastrank_glue_loads_and_validates():
+    """colbert_amd/_fastrank.so (csrc/fastrank.c: CPython glue of rank_forward's online path) is built next to the
+    library and refuses malformed calls before touching any pointer."""
+    from colbert_amd import ranker
+    fr = ranker._fastrank
+    assert fr is not None, "colbert_amd/_fastrank.so missing: run __graft_entry__.build()"
+    assert ranker._RANK_FORWARD_FN
+    import pytest
+    with pytest.raises(TypeError):
+        fr.rank_forward(1, 2, 3, 0, 32, (1, 2), 10, 4, 5, 6, 7, 8, 9)            # not a list
+    with pytest.raises(ValueError):
+        fr.rank_forward(1, 2, 3, 0, 32, [], 10, 4, 5, 6, 7, 8, 9)                # empty
+    with pytest.raises(ValueError):
+        fr.rank_forward(1, 2, 3, 0, 32, [1], 0, 4, 5, 6, 7, 8, 9)               # depth 0
+    with pytest.raises(ValueError):
+        fr.rank_forward(1, 2, 3, 0, 32, [1], 1, 0, 5, 6, 7, 8, 9)               # null input buffer
+    import ctypes
+    buf = (ctypes.c_int64 * 4)()
+    with pytest.raises(TypeError):
+        fr.rank_forward(1, 2, 3, 0, 32, [1, 2.5], 1, ctypes.addressof(buf), 5, 6, 7, 8, 9)   # a float in the list
+    with pytest.raises(OverflowError):
+        fr.rank_forward(1, 2, 3, 0, 32, [1, 2 ** 70], 1, ctypes.addressof(buf), 5, 6, 7, 8, 9)
+    # the list lands in the input buffer exactly (one- and two-digit ints, negative and > 2^60 through the general
+    # conversion) and a library error code comes back as an int: a stand-in for maxsim_rank_forward that returns -3
+    big = (ctypes.c_int64 * 9)()
+    proto = ctypes.CFUNCTYPE(ctypes.c_int, *([ctypes.c_void_p] * 2 + [ctypes.c_int] * 2 + [ctypes.c_void_p] + [ctypes.c_int] * 2 +
+                                             [ctypes.c_void_p] * 4 + [ctypes.c_int, ctypes.c_void_p]))
+    seen = {}
+
+    def stand_in(iv, q, q_dtype, lq, pids, n, depth, *rest):
+        seen.update(n=n, depth=depth, lq=lq, sync=rest[4])
+        return -3
+    cb = proto(stand_in)
+    vals = [0, 1, 2 ** 30 - 1, 2 ** 30, 2 ** 45 + 7, 2 ** 60 - 1, 2 ** 60, -5, 2 ** 63 - 1]
+    rc = fr.rank_forward(ctypes.cast(cb, ctypes.c_void_p).value, 2, 3, 0, 32, vals, 4, ctypes.addressof(big), 0, 6, 7, 8, 9)
+    assert rc == -3 and list(big) == vals
+    assert seen == {"n": 9, "depth": 4, "lq": 32, "sync": 1}

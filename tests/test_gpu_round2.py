@@ -192,6 +192,19 @@ def test_rank_forward_input_forms_and_threads(ca, golden):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not errors, errors
+    # the CPython glue (csrc/fastrank.c) and the ctypes path make the same library call: identical lists; a list the
+    # glue refuses (numpy integers) takes the general path; out-of-range pids are an error on both
+    from colbert_amd import ranker as rk
+    assert rk._fastrank is not None
+    fast = r.rank_forward(Q, pids, depth=100)
+    weird = r.rank_forward(Q, [np.int64(p) for p in pids], depth=100)
+    saved, rk._fastrank = rk._fastrank, None
+    try:
+        slow = r.rank_forward(Q, pids, depth=100)
+    finally:
+        rk._fastrank = saved
+    assert fast == slow == weird
+    assert type(fast[0]) is list and type(fast[0][0]) is int and type(fast[1][0]) is float
 
 
 # ------------------------------------------------------------------------------------------------------
