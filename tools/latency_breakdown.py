@@ -9,6 +9,8 @@ dev = "cuda"
 gen = torch.Generator(device=dev).manual_seed(0)
 nd = int(os.environ.get("NDOCS", 1000000))
 idx = F.normalize(torch.randn(nd * 180, 128, generator=gen, device=dev), dim=-1)
+if os.environ.get("DTYPE", "fp32") == "fp16":        # the reference's storage dtype (colbert_ranker.py:62)
+    idx = idx.half()
 r = colbert_amd.ColbertRanker.from_device_tensor(idx, [180] * nd)
 Q = F.normalize(torch.randn(1, 32, 128, generator=gen, device=dev), dim=-1).permute(0, 2, 1)    # [1,h,Lq] view
 lists = [torch.randperm(nd)[:1000].tolist() for _ in range(64)]
@@ -48,4 +50,4 @@ for i in range(100):
     c = torch.tensor(lists[i % 64], device=dev).view(1, -1)
     e0.record(); r.score_candidates(Qt, c); e1.record(); e1.synchronize(); ks.append(e0.elapsed_time(e1) * 1e3)
 ks.sort()
-print("  rerank kernel alone (events, fresh docs)  median %.1f us, min %.1f us  -> %.2f TB/s" % (ks[50], ks[0], 1000 * 180 * 512 / ks[50] / 1e6))
+print("  rerank kernel alone (events, fresh docs)  median %.1f us, min %.1f us  -> %.2f TB/s" % (ks[50], ks[0], 1000 * 180 * idx.element_size() * 128 / ks[50] / 1e6))
