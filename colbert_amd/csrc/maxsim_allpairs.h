@@ -328,9 +328,13 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
       //  registers -> spills)
 #define AP_PICK(sim_, pos_)                                                                                           \
   do {                                                                                                                \
-    const bool better = (sim_) > best; /* strict >: the first maximal token wins (torch.max); a NaN never does */      \
-    best = better ? (sim_) : best;                                                                                    \
-    if (AM) bidx = better ? (pos_) : bidx;                                                                            \
+    if constexpr (AM) {                                                                                               \
+      const bool better = (sim_) > best; /* strict >: the first maximal token wins (torch.max); a NaN never does */    \
+      best = better ? (sim_) : best;                                                                                  \
+      bidx = better ? (pos_) : bidx;                                                                                  \
+    } else {                                                                                                          \
+      best = __builtin_fmaxf(best, (sim_)); /* (maxNum: a NaN operand is dropped; pairs fuse into v_max3_f32) */      \
+    }                                                                                                                 \
   } while (0)
 #define AP_SCAN(PREMUL)                                                                                               \
   _Pragma("unroll") for (int b = 0; b < R; ++b) {                                                                     \

@@ -560,9 +560,17 @@ def test_allpairs_kernel_random_shapes_against_streaming_kernel(ca):
                                           torch.cuda.current_stream().cuda_stream)
             assert rc == 0, (case, rc)
             res.append((out, arg))
+        # the same kernel without arg-max tracking (maxsim_score_dense: the no-grad operator): the same scores, bit for bit
+        qa, da = (None, None) if qm is None else (qm.float().cuda(), dm.float().cuda())
+        o3 = torch.empty(nq, nd, device="cuda")
+        rc = L.maxsim_score_dense(Q.data_ptr(), D.data_ptr(), None if qa is None else qa.data_ptr(), None if da is None else da.data_ptr(),
+                                  nq, nd, Lq, Ld, h, _DT[dt], 0 if qa is None else _MDT[torch.float32], o3.data_ptr(),
+                                  torch.cuda.current_stream().cuda_stream)
+        assert rc == 0, (case, rc)
         torch.cuda.synchronize()
         (o1, a1), (o2, a2) = res
         tag = (case, nq, nd, Lq, Ld, h, str(dt), mode)
+        assert torch.equal(o1, o3), tag
         assert bool(torch.isfinite(o1).all()), tag
         torch.testing.assert_close(o1, o2, rtol=0, atol=ATOL16, msg=str(tag))
         assert bool((a1 >= 0).all()) and bool((a1 < Ld).all()), tag
