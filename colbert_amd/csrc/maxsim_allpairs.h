@@ -78,12 +78,15 @@ __device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are d
 #define AP_ABLATE_MFMA 0
 #endif
 // k-steps (0..3) in which the first-half waves (doc rows) and the second-half waves (query rows) issue their LDS-DMA
-// instructions of the next slice: the first half in A0 and A0 + 1, the second half in B0
+// instructions of the next slice: the first half in A0 and A0 + 1, the second half in B0 (R = 2: in 0 and 1, see the loop)
 #ifndef AP_DMA_A0
 #define AP_DMA_A0 0
 #endif
 #ifndef AP_DMA_B0
 #define AP_DMA_B0 1
+#endif
+#ifndef AP_DMA_BSPLIT
+#define AP_DMA_BSPLIT 0
 #endif
 
 template <int DT, int R, int QB, bool AM>
@@ -256,7 +259,11 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
     for (int i = 0; i < NF; ++i) AP_READ(0, i, aa, ab);
     // DMA instructions of this wave placed behind MFMA i of k-step ks (slots NF .. NM - 1 of a k-step carry no read)
     constexpr int SLOTS = NM > NF ? NM - NF : 1;
-    constexpr int PER_A = (NDA / 2 + SLOTS - 1) / SLOTS, PER_B = (NDB + SLOTS - 1) / SLOTS;
+    // when the second half fetches: all its instructions in one k-step, or split over two (measured per tile shape:
+    // R = 3 k-step 1 alone, R = 2 k-steps 0 and 1 (+4 %), R = 1 no difference)
+    constexpr bool BSPLIT = AP_DMA_BSPLIT != 0 || R == 2;
+    constexpr int B0 = R == 2 ? 0 : AP_DMA_B0;
+    constexpr int PER_A = (NDA / 2 + SLOTS - 1) / SLOTS, PER_B = (NDB + SLOTS - 1) / SLOTS, PER_B2 = (NDB / 2 + SLOTS - 1) / SLOTS;
 #define AP_KSTEP(ks, C0)                                                                                              \
   {                                                                                                                   \
     wait_frags((ks) & 1);                                                                                             \
@@ -272,10 +279,16 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
             if (sl_ * PER_A + t < NDA / 2) AP_DMA(st ^ 1, j < NDA ? j : 0);                                           \
           }                                                                                                           \
         }                                                                                                             \
-        if (!first_half && (ks) == AP_DMA_B0) {                                                                       \
+        if (!first_half && !BSPLIT && (ks) == B0) {                                                       \
           _Pragma("unroll") for (int t = 0; t < (NM > NF ? PER_B : NDB); ++t) {                                       \
             const int j = sl_ * PER_B + t;                                                                            \
             if (j < NDB) AP_DMA(st ^ 1, j < NDB ? j : 0);                                                             \
+          }                                                                                                           \
+        }                                                                                                             \
+        if (!first_half && BSPLIT && ((ks) == B0 || (ks) == B0 + 1)) {                                              \
+          _Pragma("unroll") for (int t = 0; t < (NM > NF ? PER_B2 : NDB / 2); ++t) {                                  \
+            const int j = ((ks) - B0) * (NDB / 2) + sl_ * PER_B2 + t;                                                 \
+            if (sl_ * PER_B2 + t < NDB / 2) AP_DMA(st ^ 1, j < NDB ? j : 0);                                          \
           }                                                                                                           \
         }                                                                                                             \
       }                                                                                                               \
