@@ -55,6 +55,11 @@ int main(void) {
     CHECK(maxsim_score_dense(dQ, dD, dqm, ddm, 1, 2, 2, 2, 3, 77, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EINVAL, "unknown dtype -> EINVAL");
     CHECK(maxsim_score_dense(NULL, dD, dqm, ddm, 1, 2, 2, 2, 3, MAXSIM_F32, MAXSIM_MASK_F32, dout, NULL) == MAXSIM_EINVAL, "NULL Q -> EINVAL");
     CHECK(strlen(maxsim_strerror(MAXSIM_EEMPTY)) > 0, "strerror");
+    /* which kernel an all-pairs shape gets (host logic only): the reference's training step -> the GEMM-blocked kernel */
+    CHECK(maxsim_score_dense_kernel(272, 544, 32, 384, 768, MAXSIM_BF16, MAXSIM_MASK_F32) == 1, "dense_kernel: training step");
+    CHECK(maxsim_score_dense_kernel(272, 544, 32, 384, 768, MAXSIM_F32, MAXSIM_MASK_F32) == 0, "dense_kernel: fp32 operands");
+    CHECK(maxsim_score_dense_kernel(1, 10, 32, 180, 128, MAXSIM_F16, MAXSIM_MASK_NONE) == 0, "dense_kernel: too few tiles");
+    CHECK(maxsim_score_dense_kernel(1, 10, 0, 180, 128, MAXSIM_F16, MAXSIM_MASK_NONE) == MAXSIM_EINVAL, "dense_kernel: Lq < 1");
   }
 
   /* (the reference's own KAT numbers, [[21, 41]], are checked from Python against the golden file) the zero-floor pair: */
