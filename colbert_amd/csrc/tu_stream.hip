@@ -50,8 +50,21 @@ int launch_stream(Params& p, hipStream_t st) {
     // short stream arrive sooner and tiles straddle fewer docs: +5-7 % at 8-16 tokens per doc, -2 % from 32 up.
     // (diagnostic: MAXSIM_VARIANT=6 forces this kernel, 8 disables it)
     const bool short_docs = p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs;
-    if (variant == 6 || (short_docs && variant == 0))
+    if (variant == 6 || (short_docs && variant == 0)) {
+      // Very short docs (<= 16 tokens on average; the 8-token multi-view config): ONE half tile per wave and twice the
+      // waves -- 16 per CU -- instead of two tiles per wave and 8 waves.  These launches are bound by how many independent
+      // doc streams are in flight, not by bytes in flight per stream: 256 queries x 1000 eight-token docs 0.200 -> 0.185 ms
+      // (4-token docs 0.134 -> 0.111, 16-token docs 0.355 -> 0.351; 24-token docs 0.570 -> 0.575: those keep two tiles).
+      // Workgroups of 8 waves when there are enough of them to fill the chip (fewer dispatches), of 4 waves otherwise.
+      // (diagnostic: MAXSIM_F32H_SHAPE=1/2/3 forces 4 x 1 / 8 x 1 / 4 x 2)
+      const int shape = MAXSIM_KNOB("MAXSIM_F32H_SHAPE", 0);
+      const bool very_short = p.n_tokens <= 16 * p.n_docs;
+      const bool many = (int64_t)p.nq * ((p.ncand + 511) / 512) >= 256;
+      const int pick = shape ? shape : (!very_short ? 3 : many ? 2 : 1);
+      if (pick == 2) return p.Lq <= 16 ? launch_stream_f32h<8, 1, 1>(p, st) : launch_stream_f32h<8, 2, 1>(p, st);
+      if (pick == 1) return p.Lq <= 16 ? launch_stream_f32h<4, 1, 1>(p, st) : launch_stream_f32h<4, 2, 1>(p, st);
       return p.Lq <= 16 ? launch_stream_f32h<4, 1, 2>(p, st) : launch_stream_f32h<4, 2, 2>(p, st);
+    }
     if (p.Lq <= 16 && variant != 4) {  // (Lq <= 16 implies a single query slice)
 #ifdef MAXSIM_DIAG
       if (variant == 1) return launch_stream_v<MODE, DT, 4, NT0, 1, 16>(p, st);
