@@ -17,7 +17,8 @@ OK, EINVAL, EEMPTY, ERANGE, ELAUNCH = 0, -1, -2, -3, -4
 SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_rerank", "maxsim_topk",
            "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
            "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_rank_forward_workspace_bytes", "maxsim_doc_table_bytes",
-           "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel")
+           "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel", "maxsim_worklist_bytes",
+           "maxsim_rerank_counted", "maxsim_topk_counted")
 
 
 class IndexView(ctypes.Structure):
@@ -74,6 +75,12 @@ def _load():
     lib.maxsim_score_dense_kernel.argtypes = [i32] * 7
     lib.maxsim_shard_candidates.restype = i32
     lib.maxsim_shard_candidates.argtypes = [vp, i32, i32, i64, i64, vp, vp, vp, vp]
+    lib.maxsim_worklist_bytes.restype = i64
+    lib.maxsim_worklist_bytes.argtypes = [i32, i32]
+    lib.maxsim_rerank_counted.restype = i32
+    lib.maxsim_rerank_counted.argtypes = [ivp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp]
+    lib.maxsim_topk_counted.restype = i32
+    lib.maxsim_topk_counted.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
     return lib

@@ -14,6 +14,7 @@
 #include "maxsim_launch.h"
 #include "maxsim_shard.h"
 #include "maxsim_topk.h"
+#include "maxsim_worklist.h"
 
 using namespace maxsim;
 
@@ -203,9 +204,18 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   return check_launch();
 }
 
+int64_t maxsim_worklist_bytes(int nq, int ncand) {
+  if (nq < 0 || ncand < 0) return 0;
+  // header + item_start[nq + 1] + at most one wave item per candidate slot
+  return (worklist_items_word(nq) + 2 * ((int64_t)nq * ncand + 1)) * (int64_t)sizeof(int32_t);
+}
+
+constexpr int LIST_MIN_ITEMS = 1792;  // 448 workgroups of 4 waves: pick_docs_per_wave's rule, applied on the device
+
 static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, const int32_t* q_len,
                        const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
-                       hipStream_t st) {
+                       hipStream_t st, const int32_t* cand_count = nullptr, void* worklist = nullptr,
+                       int64_t worklist_bytes = 0) {
   const int h = iv.h, index_dtype = iv.index_dtype;
   const int64_t n_tokens = iv.n_tokens, n_docs = iv.n_docs;
   if (nq < 0 || ncand < 0 || Lq < 0 || h < 0 || n_tokens < 0 || n_docs < 0) return MAXSIM_EINVAL;
@@ -236,6 +246,21 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
   p.mask_dtype = MAXSIM_MASK_NONE;
   const bool aligned = (((uintptr_t)Q | (uintptr_t)iv.index) & 15) == 0;  // the streaming kernels move 16-byte pieces
   const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
+  // counted rows (doc shards, ANN lists): the device builds a dense list of wave items and a fixed grid walks it.  Short
+  // docs keep the static grid (its half-tile kernel); so does every shape without a streaming kernel for h = 128.
+  const bool short_docs = n_docs > 0 && n_tokens <= 24 * n_docs;
+  if (h == 128 && stream_ok && cand_count && worklist && ((uintptr_t)worklist & 15) == 0 && !short_docs &&
+      worklist_bytes >= maxsim_worklist_bytes(nq, ncand) && ncand < (1 << WL_SLOT_BITS)) {
+    p.worklist = worklist;
+    const int D0 = stream_list_docs_per_item(p);
+    int32_t* const wl = (int32_t*)worklist;
+    hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, LIST_MIN_ITEMS, wl);
+    hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
+    if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
+    const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * LIST_MIN_ITEMS + nq;
+    const int64_t max_items = by_rows > small ? by_rows : small;
+    return for_query_slices(p, [&] { return launch_stream_list(p, index_dtype, max_items, st); });
+  }
   if (h == 128 && stream_ok) {
     if (Lq <= 32) {  // small launches of a 16-bit index: docs split over several waves
       const int rc = launch_stream_small(p, index_dtype, st);
@@ -275,6 +300,14 @@ int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, co
   return rerank_impl(*iv, Q, q_dtype, q_len, q_mask, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream);
 }
 
+int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
+                          const uint8_t* q_mask, const int64_t* cand_pids, const int32_t* cand_count, int nq, int ncand,
+                          int Lq, float* scores, void* worklist, int64_t worklist_bytes, void* stream) {
+  if (!iv) return MAXSIM_EINVAL;
+  return rerank_impl(*iv, Q, q_dtype, q_len, q_mask, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream, cand_count,
+                     worklist, worklist_bytes);
+}
+
 int64_t maxsim_doc_table_bytes(int64_t n_docs) { return n_docs > 0 ? n_docs * 16 : 0; }
 
 int maxsim_build_doc_table(const int64_t* tok_offsets, const int32_t* doclens, const int32_t* pad_len,
@@ -300,22 +333,37 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
 
 // short lists: rank by counting, ncand / 16 workgroups per query (maxsim_topk.h)
 static int topk_count(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
-                      int64_t* out_pids, int32_t* counter, uint32_t* done_flag, uint32_t ticket, hipStream_t st) {
+                      int64_t* out_pids, int32_t* counter, uint32_t* done_flag, uint32_t ticket, hipStream_t st,
+                      const int32_t* counts = nullptr) {
   const int groups = (ncand + TOPK_CAND_PER_WG - 1) / TOPK_CAND_PER_WG;
   if ((int64_t)nq * groups > 0x7fffffffLL) return MAXSIM_ERANGE;
   hipLaunchKernelGGL(k_topk_count, dim3((unsigned)(nq * groups)), dim3(256), 0, st, scores, pids, ncand, k, out_scores,
-                     out_pids, groups, counter, done_flag, ticket);
+                     out_pids, groups, counter, done_flag, ticket, counts);
   return check_launch();
 }
 
+static int topk_impl(const float* scores, const int64_t* pids, const int32_t* counts, int nq, int ncand, int k,
+                     float* out_scores, int64_t* out_pids, void* stream);
+
 int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
                 int64_t* out_pids, void* stream) {
+  return topk_impl(scores, pids, nullptr, nq, ncand, k, out_scores, out_pids, stream);
+}
+
+int maxsim_topk_counted(const float* scores, const int64_t* pids, const int32_t* counts, int nq, int ncand, int k,
+                        float* out_scores, int64_t* out_pids, void* stream) {
+  return topk_impl(scores, pids, counts, nq, ncand, k, out_scores, out_pids, stream);
+}
+
+static int topk_impl(const float* scores, const int64_t* pids, const int32_t* counts, int nq, int ncand, int k,
+                     float* out_scores, int64_t* out_pids, void* stream) {
   if (nq < 0 || ncand < 0 || k < 1) return MAXSIM_EINVAL;
   if (ncand == 0) return MAXSIM_EEMPTY;
   if (ncand > 16384) return MAXSIM_ERANGE;
   if (nq == 0) return MAXSIM_OK;
   if (!scores || !out_scores || !out_pids) return MAXSIM_EINVAL;
-  if (ncand <= 2048) return topk_count(scores, pids, nq, ncand, k, out_scores, out_pids, nullptr, nullptr, 0, (hipStream_t)stream);
+  if (ncand <= 2048)
+    return topk_count(scores, pids, nq, ncand, k, out_scores, out_pids, nullptr, nullptr, 0, (hipStream_t)stream, counts);
   int P = 2;
   while (P < ncand) P <<= 1;
   const int ldsb = P * 8;

@@ -51,6 +51,9 @@ struct Params {
   int dpw;     // docs per workgroup
   int nchunk;  // ceil(ncand / dpw)
   int split;   // split-doc kernels: waves per doc (2 or 4); otherwise 1
+  // dense work list (maxsim_worklist.h; counted candidate rows -- doc shards, ANN lists): NULL, or the device-built list of
+  // (query, first slot, docs) wave items the LIST kernels walk instead of the static (query, chunk) grid
+  const void* worklist;
 };
 
 // Kernel arguments: the read-only tables are passed as individual `const __restrict__` pointers (not inside
@@ -66,7 +69,8 @@ struct Scalars {
       const int32_t* __restrict__ a_doclens, const int32_t* __restrict__ a_pad_len,                         \
       const void* __restrict__ a_Q, const int32_t* __restrict__ a_q_len, const int64_t* __restrict__ a_cand, \
       float* __restrict__ a_scores, const void* __restrict__ a_q_mask, const void* __restrict__ a_d_mask,   \
-      int32_t* __restrict__ a_argmax, const void* __restrict__ a_doc_table, const maxsim::Scalars sc
+      int32_t* __restrict__ a_argmax, const void* __restrict__ a_doc_table, const void* __restrict__ a_worklist, \
+      const maxsim::Scalars sc
 #define KARGS_TO_PARAMS                                                                                     \
   maxsim::Params p;                                                                                         \
   p.index = a_index; p.n_tokens = sc.n_tokens; p.tok_offsets = a_tok_offsets; p.doclens = a_doclens;        \
@@ -74,10 +78,10 @@ struct Scalars {
   p.nq = sc.nq; p.ncand = sc.ncand; p.Lq = sc.Lq; p.h = sc.h; p.scores = a_scores; p.q_mask = a_q_mask;     \
   p.d_mask = a_d_mask; p.mask_dtype = sc.mask_dtype; p.Ld = sc.Ld; p.dpw = sc.dpw; p.nchunk = sc.nchunk;         \
   p.q_dtype = sc.q_dtype; p.argmax = a_argmax; p.q_tok0 = sc.q_tok0; p.accum = sc.accum; p.doc_table = a_doc_table;       \
-  p.split = sc.split
+  p.split = sc.split; p.worklist = a_worklist
 #define KARGS_PASS(p)                                                                                       \
   (p).index, (p).tok_offsets, (p).doclens, (p).pad_len, (p).Q, (p).q_len, (p).cand, (p).scores, (p).q_mask, \
-      (p).d_mask, (p).argmax, (p).doc_table, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
+      (p).d_mask, (p).argmax, (p).doc_table, (p).worklist, maxsim::Scalars { (p).n_tokens, (p).n_docs, (p).nq, (p).ncand, (p).Lq, (p).h,             \
                                     (p).mask_dtype, (p).Ld, (p).dpw, (p).nchunk, (p).q_dtype, (p).q_tok0, (p).accum,       \
                                     (p).split }
 

@@ -83,6 +83,10 @@ inline int pick_docs_per_wave(const Params& p, int waves) {
 // tu_stream.hip: the h = 128 register-query kernel.  index_dtype: MAXSIM_F32 / F16 / BF16 / F32_FAST / F32_BF16X3.
 int launch_stream_rerank(Params& p, int index_dtype, hipStream_t st);
 int launch_stream_dense_f32(Params& p, hipStream_t st);
+// tu_stream.hip, counted candidate rows: the same kernel walking a device-built work list (maxsim_worklist.h) on a fixed
+// grid.  max_items = an upper bound of the list length known on the host (sizes the grid below its cap).
+int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_t st);
+int stream_list_docs_per_item(const Params& p);
 // tu_stream_small.hip: small launches of the same kernel with each doc split over several waves (bit-identical scores).
 // MAXSIM_ERANGE = not a launch this form serves (take the regular path).
 int launch_stream_small(Params& p, int index_dtype, hipStream_t st);

@@ -22,6 +22,7 @@
 // There is no workgroup barrier: waves pace their own ring with counted s_waitcnt vmcnt.
 #pragma once
 #include "maxsim_common.h"
+#include "maxsim_worklist.h"
 
 namespace maxsim {
 
@@ -532,9 +533,13 @@ constexpr int QT_2X16 = 48;  // 32 query tokens as two 16-column blocks of v_mfm
 //           Measured (tools/bench_small.py, 1 query x 1000 docs x 180 tokens): fp16 index 31 -> 17 us; the fp32 index
 //           is already bandwidth-bound with one wave per doc (16 KiB tiles: 16 MB in flight) and does not gain.
 constexpr int SPLIT_MAX_DOCS = 8;  // docs per team of waves in a SPLITK launch (their parked maxima live in LDS)
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
+// LIST (counted candidate rows, maxsim_worklist.h): the grid is fixed and every WAVE walks the device-built list of wave
+//   items (query, first slot, docs): item = global wave id, + waves in the grid, ...; the waves of a workgroup share
+//   nothing (each holds its own query registers), so they may be on different queries.
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false, bool LIST = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
+  static_assert(!LIST || (MODE == MODE_RERANK && !SPLITK), "work-list form: rerank, unsplit");
   static_assert(!SPLITK || (MODE == MODE_RERANK && QT == QT_2X16 && WAVES == 4), "split form: two 16-column blocks only");
   static_assert(QT == 32 || (MODE == MODE_RERANK && ((QT == 16 && DT == MAXSIM_F32) ||
                                                      (QT == QT_2X16 && DT != F32S))),
@@ -545,15 +550,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   constexpr int ROWB = T::ROWB, TILE = T::TILE, NDMA = T::NDMA, RPD = T::RPD, LPR = T::LPR, NRD = T::NRD, NP = T::NP;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  int qi, chunk;
-  wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
   // unsplit: every wave has its own docs.  SPLITK: `split` consecutive waves form a team that shares dpwv docs; wave
   // `part` of the team streams the part-th slice of each doc (slices are whole 32-row tiles, cut as evenly as possible)
   const int split = SPLITK ? p.split : 1;
   const int team = SPLITK ? wave / split : wave, part = SPLITK ? wave - team * split : 0;
-  const int dpwv = SPLITK ? p.dpw / (WAVES / split) : p.dpw / WAVES;  // docs per wave / per team (<= 64; SPLITK: <= SPLIT_MAX_DOCS)
-  const int c_begin = chunk * p.dpw + team * dpwv;  // this wave's candidates: [c_begin, c_begin + ndoc)
-  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  // one wave item: candidates [c_begin, c_begin + ndoc) of query qi
+  auto wave_item = [&](const int qi, const int c_begin, const int ndoc) __attribute__((always_inline)) {
   DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
   if constexpr (SPLITK) {
     const int per = (((dl.len + 31) >> 5) + split - 1) / split * 32;  // rows per slice
@@ -1027,6 +1029,24 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   } else {
     red.drain(C, dl, lane);
     if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
+  }
+  };  // wave_item
+  if constexpr (LIST) {
+    // the wave's items: global wave id, + waves in the grid, ... (uniform scalar loads from the work list)
+    const int32_t* const wl = (const int32_t*)p.worklist;
+    const int wl_total = uni(wl[0]);
+    const int2* const wl_items = (const int2*)(wl + worklist_items_word(p.nq));
+    for (int item = (int)blockIdx.x * WAVES + wave; item < wl_total; item += (int)gridDim.x * WAVES) {
+      const int2 e = wl_items[item];
+      __builtin_amdgcn_s_setprio(0);
+      wave_item(uni(e.x), uni(e.y) & ((1 << WL_SLOT_BITS) - 1), uni(e.y) >> WL_SLOT_BITS);
+    }
+  } else {
+    int qi, chunk;
+    wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
+    const int dpwv = SPLITK ? p.dpw / (WAVES / split) : p.dpw / WAVES;  // docs per wave / per team (<= 64; SPLITK: <= SPLIT_MAX_DOCS)
+    const int c_begin = chunk * p.dpw + team * dpwv;
+    wave_item(qi, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
   }
 }
 

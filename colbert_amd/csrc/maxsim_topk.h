@@ -32,17 +32,25 @@ constexpr int TOPK_CAND_PER_WG = 16;
 __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ scores, const int64_t* __restrict__ pids,
                                                     int ncand, int k, float* __restrict__ out_s,
                                                     int64_t* __restrict__ out_p, int groups, int32_t* counter,
-                                                    uint32_t* done_flag, uint32_t ticket) {
+                                                    uint32_t* done_flag, uint32_t ticket,
+                                                    const int32_t* __restrict__ counts) {
   __shared__ uint64_t keys[2048];
   const int tid = threadIdx.x;
   const int q = blockIdx.x / groups, g = blockIdx.x - q * groups;
-  const float* srow = scores + (int64_t)q * ncand;
+  const int row_w = ncand;  // row pitch of scores / pids
+  // counted rows: only the first counts[q] slots of the row are candidates (the rest is (-inf, -1) padding, which is also
+  // what the slots [n, k) of the output receive) -- the groups past them have nothing to rank
+  if (counts) {
+    ncand = min(max(counts[q], 0), row_w);
+    if (g > 0 && g * TOPK_CAND_PER_WG >= ncand) return;  // (counts are never combined with done_flag)
+  }
+  const float* srow = scores + (int64_t)q * row_w;
   const int n16 = (ncand + 15) & ~15;
   for (int i = tid; i < n16; i += 256)
     keys[i] = i < ncand ? (((uint64_t)orderable(srow[i]) << 32) | (uint32_t)(~(uint32_t)i)) : 0ull;  // 0 < every real key
   __syncthreads();
   const int c = g * TOPK_CAND_PER_WG + (tid >> 4), part = tid & 15;
-  const uint64_t mine = keys[min(c, n16 - 1)];
+  const uint64_t mine = keys[max(min(c, n16 - 1), 0)];
   int above = 0;
 #pragma unroll 4
   for (int j = part; j < n16; j += 16) above += keys[j] > mine ? 1 : 0;
@@ -54,7 +62,7 @@ __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ sc
   if (part == 0 && c < ncand && above < k) {
     const int pos = (int)(~(uint32_t)mine);
     const float s = unorderable((uint32_t)(mine >> 32));
-    const int64_t pid = pids ? pids[(int64_t)q * ncand + pos] : (int64_t)pos;
+    const int64_t pid = pids ? pids[(int64_t)q * row_w + pos] : (int64_t)pos;
     float* os = out_s + (int64_t)q * k + above;
     int64_t* op = out_p + (int64_t)q * k + above;
     if (done_flag) {  // the host may read these while the kernel is still running: system-scope write-through

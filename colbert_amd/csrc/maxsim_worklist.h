@@ -1,0 +1,100 @@
+// maxsim_worklist.h -- the dense work list of counted candidate rows.
+//
+// A candidate matrix whose rows are only partly live -- one rank's share of a doc-sharded step (maxsim_shard_candidates:
+// ~1/N of every 1000-wide row), or the distinct pids of an ANN search (maxsim_embedding_ids_to_pids) -- is a bad fit for
+// the static (query, chunk) grid of the streaming kernels: most of the grid is all-padding workgroups, the last live
+// chunk of every row leaves waves of its workgroup without docs (the workgroup keeps its LDS until its one busy wave is
+// done), and nothing of this is known on the host without a synchronisation.  Here the device builds, from the per-row
+// live counts, a list of WAVE ITEMS (query, first slot, docs) -- every item about as many docs as a wave's stream should
+// hold, a row's docs dealt evenly over its items -- and the LIST form of the streaming kernel (maxsim_stream.h) runs a
+// fixed grid whose waves walk that list: item = wave id, + waves in the grid, ...  No host sync, no all-padding
+// workgroups, every wave of every workgroup busy.
+//
+// Layout of the work list (device memory, int32 words):
+//   [0] number of wave items   [1] docs per item the builder settled on   [2] live candidates in all rows   [3..15] 0
+//   [16 .. 16 + nq]            item_start[q] (exclusive prefix sum of the rows' item counts; [nq] = word 0)
+//   then, 16-byte aligned:     items[] as int2 {query, first slot | docs << 24}
+#pragma once
+#include "maxsim_common.h"
+
+namespace maxsim {
+
+constexpr int WL_HEADER_WORDS = 16;
+constexpr int WL_SLOT_BITS = 24;  // first slot < 2^24; docs per item <= 64
+__host__ __device__ inline int64_t worklist_items_word(int nq) { return (WL_HEADER_WORDS + (int64_t)nq + 1 + 3) & ~(int64_t)3; }
+
+__device__ __forceinline__ int wl_row_count(const int32_t* __restrict__ counts, int q, int ncand) {
+  return min(max(counts[q], 0), ncand);
+}
+
+// One workgroup: (1) the number of live candidates -> docs per wave item D (the host's target D0 = a ~1.4 k-token stream,
+// halved while the launch would have fewer than `min_items` items: a small launch is better off with more, shorter
+// streams -- the rule pick_docs_per_wave applies on the host to static grids); (2) exclusive scan of ceil(count / D).
+static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __restrict__ counts, int nq, int ncand, int D0,
+                                                        int min_items, int32_t* __restrict__ wl) {
+  __shared__ long long red[16];
+  __shared__ int wsum[16];
+  __shared__ int carry_s, D_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long live = 0;
+  for (int q = tid; q < nq; q += 1024) live += wl_row_count(counts, q, ncand);
+  for (int o = 32; o > 0; o >>= 1) live += __shfl_xor(live, o);
+  if (lane == 0) red[wave] = live;
+  __syncthreads();
+  if (tid == 0) {
+    long long t = 0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    int D = D0 < 1 ? 1 : (D0 > 64 ? 64 : D0);
+    while (D > 1 && (t + D - 1) / D < min_items) D = (D + 1) / 2;
+    D_s = D;
+    carry_s = 0;
+    wl[1] = D;
+    wl[2] = (int32_t)(t > 0x7fffffffLL ? 0x7fffffffLL : t);
+    for (int i = 3; i < WL_HEADER_WORDS; ++i) wl[i] = 0;
+  }
+  __syncthreads();
+  const int D = D_s;
+  int32_t* const item_start = wl + WL_HEADER_WORDS;
+  for (int q0 = 0; q0 < nq; q0 += 1024) {
+    const int q = q0 + tid;
+    const int w = q < nq ? (wl_row_count(counts, q, ncand) + D - 1) / D : 0;
+    int incl = w;  // inclusive scan inside the wave
+    for (int o = 1; o < 64; o <<= 1) {
+      const int up = __shfl_up(incl, o);
+      incl += lane >= o ? up : 0;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int base = carry_s;
+    for (int k = 0; k < wave; ++k) base += wsum[k];
+    if (q < nq) item_start[q] = base + incl - w;
+    __syncthreads();
+    if (tid == 1023) carry_s = base + incl;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    item_start[nq] = carry_s;
+    wl[0] = carry_s;
+  }
+}
+
+// One wave per query: the row's items (its docs dealt evenly: item j of w takes slots [j c / w, (j + 1) c / w)) and the
+// -inf tail of the row's scores (slots past the live count are padding slots: what the static kernels write there).
+static __global__ void __launch_bounds__(64) k_worklist_fill(const int32_t* __restrict__ counts, int nq, int ncand,
+                                                      int32_t* __restrict__ wl, float* __restrict__ scores,
+                                                      int fill_tail) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  const int c = wl_row_count(counts, q, ncand);
+  const int D = wl[1];
+  const int w = (c + D - 1) / D;
+  const int base = wl[WL_HEADER_WORDS + q];
+  int2* const items = (int2*)(wl + worklist_items_word(nq));
+  for (int j = lane; j < w; j += 64) {
+    const int b = (int)((long long)j * c / w), e = (int)((long long)(j + 1) * c / w);
+    items[base + j] = make_int2(q, b | ((e - b) << WL_SLOT_BITS));
+  }
+  if (fill_tail)
+    for (int i = c + lane; i < ncand; i += 64) scores[(int64_t)q * ncand + i] = NEG_INF;
+}
+
+}  // namespace maxsim

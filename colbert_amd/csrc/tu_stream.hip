@@ -111,4 +111,46 @@ int launch_stream_rerank(Params& p, int index_dtype, hipStream_t st) {
 
 int launch_stream_dense_f32(Params& p, hipStream_t st) { return launch_stream<MODE_DENSE, MAXSIM_F32>(p, st); }
 
+// ---- counted candidate rows: the work-list form (maxsim_worklist.h) ------------------------------------------------
+namespace {
+template <int DT, int QT>
+int launch_list_v(Params& p, int max_wgs, hipStream_t st) {
+  constexpr int WAVES = 4;
+  constexpr int NT = (StreamTraits<DT>::TILE == 16384) ? 1 : 2;
+  const int ldsb = WAVES * NT * StreamTraits<DT>::TILE;
+  auto kern = k_maxsim_stream<MODE_RERANK, DT, WAVES, NT, 0, QT, false, true>;
+  int rc = allow_lds(kern, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)max_wgs), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  return check_launch();
+}
+}  // namespace
+
+int stream_list_docs_per_item(const Params& p) {
+  double avg = p.n_docs > 0 ? (double)p.n_tokens / (double)p.n_docs : 1.0;
+  if (avg < 1.0) avg = 1.0;
+  int d = (int)(1440.0 / avg + 0.5);
+  const int knob = MAXSIM_KNOB("MAXSIM_DPW", 0);
+  if (knob > 0) d = knob;
+  return d < 1 ? 1 : (d > 64 ? 64 : d);
+}
+
+// The grid: enough workgroups for every item the rows could hold (4 wave items each), capped -- past the cap the waves
+// loop.  A few resident rounds keep the end of the launch balanced by the dispatcher without paying one dispatch per item.
+int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_t st) {
+  const int cap = MAXSIM_KNOB("MAXSIM_LIST_WGS", 4096);
+  int64_t wgs = (max_items + 3) / 4;
+  if (wgs < 1) wgs = 1;
+  if (wgs > cap) wgs = cap;
+  if (p.Lq <= 16 && index_dtype == MAXSIM_F32) return launch_list_v<MAXSIM_F32, 16>(p, (int)wgs, st);
+  switch (index_dtype) {
+    case MAXSIM_F32: return launch_list_v<MAXSIM_F32, QT_2X16>(p, (int)wgs, st);
+    case MAXSIM_F32_FAST: return launch_list_v<MAXSIM_F32_FAST, 32>(p, (int)wgs, st);
+    case MAXSIM_F32_BF16X3: return launch_list_v<MAXSIM_F32_BF16X3, QT_2X16>(p, (int)wgs, st);
+    case MAXSIM_F16: return launch_list_v<MAXSIM_F16, QT_2X16>(p, (int)wgs, st);
+    case MAXSIM_BF16: return launch_list_v<MAXSIM_BF16, QT_2X16>(p, (int)wgs, st);
+    default: return MAXSIM_EINVAL;
+  }
+}
+
 }  // namespace maxsim

@@ -195,11 +195,14 @@ class ColbertRanker:
                               _ptr(self.d_doclens), _ptr(self.d_pad_len), self.n_docs, _ptr(self.d_doc_table))
 
     # ------------------------------------------------------------------------------------------
-    def score_candidates(self, Q, cand_pids, q_len=None, q_mask=None):
+    def score_candidates(self, Q, cand_pids, q_len=None, q_mask=None, cand_count=None):
         """Q [nq, Lq, h] (token-major), cand_pids [nq, ncand] int64 LOCAL pids (<0 = padding slot)
         -> scores [nq, ncand] fp32 on the device.  ``q_len`` [nq] drops the tokens from that position on, ``q_mask``
         [nq, Lq] (0 = dropped) any tokens -- the batched form of the per-query ``keep_nonzero`` (training_utils.py:48-53)
-        the reference applies to ``q_active_padding`` at dense_server_client.py:45."""
+        the reference applies to ``q_active_padding`` at dense_server_client.py:45.
+        ``cand_count`` [nq] int32 (device): rows are COUNTED -- row q's live entries are its first ``cand_count[q]`` slots,
+        every later slot is negative (``shard_candidates`` / ``embedding_ids_to_pids`` rows).  Same scores; the launch is
+        scheduled from a device-built dense work list instead of the full-width grid (``maxsim_rerank_counted``)."""
         dev = self.device
         if dev.type != "cuda":
             raise RuntimeError("colbert_amd scores on the GPU only: the index must live in HBM (libmaxsim has no CPU path)")
@@ -218,15 +221,24 @@ class ColbertRanker:
             qm = (q_mask.to(dev) != 0).to(torch.uint8).contiguous()            # q_word_mask.bool(), training_utils.py:50
         scores = torch.empty(nq, ncand, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.lib.maxsim_rerank_ex(ctypes.byref(self._iv), _ptr(Q), _DT[qdt], _ptr(ql), _ptr(qm), _ptr(cand),
-                                           nq, ncand, Lq, _ptr(scores), _stream(dev))
+            if cand_count is None:
+                rc = _lib.lib.maxsim_rerank_ex(ctypes.byref(self._iv), _ptr(Q), _DT[qdt], _ptr(ql), _ptr(qm), _ptr(cand),
+                                               nq, ncand, Lq, _ptr(scores), _stream(dev))
+            else:
+                cc = cand_count.to(device=dev, dtype=torch.int32).contiguous()
+                assert cc.numel() == nq
+                nbytes = int(_lib.lib.maxsim_worklist_bytes(nq, ncand))
+                wl = torch.empty(nbytes, dtype=torch.uint8, device=dev)      # caching allocator: no HIP call in steady state
+                rc = _lib.lib.maxsim_rerank_counted(ctypes.byref(self._iv), _ptr(Q), _DT[qdt], _ptr(ql), _ptr(qm), _ptr(cand),
+                                                    _ptr(cc), nq, ncand, Lq, _ptr(scores), _ptr(wl), nbytes, _stream(dev))
         if rc == _lib.EEMPTY:
             raise AssertionError("len(pids) > 0")  # colbert_ranker.py:76
-        _lib.check(rc, "maxsim_rerank_ex")
+        _lib.check(rc, "maxsim_rerank_ex" if cand_count is None else "maxsim_rerank_counted")
         return scores
 
-    def topk(self, scores, pids, k):
-        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k])."""
+    def topk(self, scores, pids, k, counts=None):
+        """Per-query top-k (score desc): scores [nq, n] fp32, pids [nq, n] int64 or None -> ([nq,k], [nq,k]).
+        ``counts`` [nq] int32: counted rows (see ``score_candidates``): only the live slots are ranked."""
         dev = scores.device
         nq, n = scores.shape
         out_s = torch.empty(nq, k, dtype=torch.float32, device=dev)
@@ -234,16 +246,22 @@ class ColbertRanker:
         scores = scores.contiguous()
         pids = None if pids is None else pids.to(device=dev, dtype=torch.int64).contiguous()
         with torch.cuda.device(dev):
-            rc = _lib.lib.maxsim_topk(_ptr(scores), _ptr(pids), nq, n, k, _ptr(out_s), _ptr(out_p), _stream(dev))
+            if counts is None:
+                rc = _lib.lib.maxsim_topk(_ptr(scores), _ptr(pids), nq, n, k, _ptr(out_s), _ptr(out_p), _stream(dev))
+            else:
+                cc = counts.to(device=dev, dtype=torch.int32).contiguous()
+                rc = _lib.lib.maxsim_topk_counted(_ptr(scores), _ptr(pids), _ptr(cc), nq, n, k, _ptr(out_s), _ptr(out_p),
+                                                  _stream(dev))
         _lib.check(rc, "maxsim_topk")
         return out_p, out_s
 
-    def rerank_batch(self, Q, cand_pids, depth=10, q_len=None, q_mask=None):
+    def rerank_batch(self, Q, cand_pids, depth=10, q_len=None, q_mask=None, cand_count=None):
         """Batched form of the per-query loop dense_server_client.py:44-48: one launch for all queries.
-        Returns device tensors (pids [nq,k], scores [nq,k]) with k = min(depth, ncand)."""
-        scores = self.score_candidates(Q, cand_pids, q_len, q_mask)
+        Returns device tensors (pids [nq,k], scores [nq,k]) with k = min(depth, ncand).  ``cand_count``: see
+        ``score_candidates`` (counted rows, e.g. straight from ``embedding_ids_to_pids(trim=False)``)."""
+        scores = self.score_candidates(Q, cand_pids, q_len, q_mask, cand_count)
         k = min(int(depth), scores.size(1))
-        return self.topk(scores, cand_pids, k)
+        return self.topk(scores, cand_pids, k, cand_count)
 
     # ------------------------------------------------------------------------------------------
     def embedding_ids_to_pids(self, embedding_ids, trim=True):

@@ -35,24 +35,27 @@ def localize(cand_global, lo, hi):
     return torch.where(inr, cand_global - lo, torch.full_like(cand_global, -1)), inr
 
 
-def shard_candidates(cand_global, lo, hi):
+def shard_candidates(cand_global, lo, hi, with_counts=False):
     """This shard's candidates moved to the front of every row, in list order, as (local pids, global pids), both
-    ``[nq, ncand]`` with -1 in the tail.  The row width is NOT cut (no host sync): the rerank kernel's trailing
-    all-padding waves retire at once.  Device tensors run ``maxsim_shard_candidates``; CPU tensors (the gloo tests,
+    ``[nq, ncand]`` with -1 in the tail; ``with_counts`` adds the per-row live count (int32 [nq]).  The row width is NOT
+    cut and nothing is read back (no host sync): the counts stay on the device, where the rerank builds its work list
+    from them (``maxsim_rerank_counted``).  Device tensors run ``maxsim_shard_candidates``; CPU tensors (the gloo tests,
     whose scorer is injected) the same stable partition in torch."""
     nq, ncand = cand_global.shape
     if cand_global.is_cuda:
         cg = cand_global.to(torch.int64).contiguous()
         loc, gp = torch.empty_like(cg), torch.empty_like(cg)
+        cnt = torch.empty(nq, dtype=torch.int32, device=cg.device)
         with torch.cuda.device(cg.device):
             rc = _lib.lib.maxsim_shard_candidates(cg.data_ptr(), nq, ncand, int(lo), int(hi), loc.data_ptr(), gp.data_ptr(),
-                                                  None, torch.cuda.current_stream(cg.device).cuda_stream)
+                                                  cnt.data_ptr(), torch.cuda.current_stream(cg.device).cuda_stream)
         _lib.check(rc, "maxsim_shard_candidates")
-        return loc, gp
+        return (loc, gp, cnt) if with_counts else (loc, gp)
     loc, inr = localize(cand_global, lo, hi)
     gp = torch.where(inr, cand_global, torch.full_like(cand_global, -1))
     order = torch.argsort((~inr).to(torch.int8), dim=1, stable=True)
-    return torch.gather(loc, 1, order), torch.gather(gp, 1, order)
+    loc, gp = torch.gather(loc, 1, order), torch.gather(gp, 1, order)
+    return (loc, gp, inr.sum(1).to(torch.int32)) if with_counts else (loc, gp)
 
 
 def global_strides(local_doclens, group=None, device=None):
@@ -109,6 +112,10 @@ class ShardedRanker:
         self.group = group
         self.score_fn = score_fn if score_fn is not None else local_ranker.score_candidates
         self.topk_fn = topk_fn if topk_fn is not None else local_ranker.topk
+        # the product scorer / top-k take the per-row live counts (counted rows: maxsim_rerank_counted / maxsim_topk_counted);
+        # injected ones (CPU tests) get the plain signature unless they say otherwise
+        self.score_counted = score_fn is None
+        self.topk_counted = topk_fn is None
         self.force_exchange = False   # diagnostic: run the exchange + merge even at world size 1 (bench.py --force-dist)
         self.exchange_events = None   # diagnostic: a list here collects (start, stop) HIP events of every exchange + merge
         # bucket by the strides of the whole index (see the module docstring); every rank must construct its
@@ -121,14 +128,18 @@ class ShardedRanker:
         """Scores this shard's share of every query's GLOBAL candidate list and returns its local top-k with global pids:
         (pids [nq,k], scores [nq,k]); slots beyond a query's local candidates are (-1, -inf)."""
         k = min(int(depth), cand_global.size(1))
-        cand_local, gp = shard_candidates(cand_global, self.lo, self.hi)
+        cand_local, gp, cnt = shard_candidates(cand_global, self.lo, self.hi, with_counts=True)
         kw = {}
         if q_len is not None:
             kw["q_len"] = q_len
         if q_mask is not None:
             kw["q_mask"] = q_mask
+        if self.score_counted:
+            kw["cand_count"] = cnt
         scores = self.score_fn(Q, cand_local, **kw)
         gp = gp.to(scores.device)
+        if self.topk_counted:
+            return self.topk_fn(scores, gp, k, cnt)
         return self.topk_fn(scores, gp, k)
 
     def _world(self):

@@ -19,6 +19,9 @@
  *   maxsim_rank_forward <- ONE call of ColbertRanker.rank_forward       colbert/ranking/colbert_ranker.py:75-137
  *                          (the reference's online call shape, colbert/indexing/faiss_indexers.py:234)
  *   maxsim_build_doc_table <- index state set up by init_ranker         colbert/ranking/colbert_ranker.py:31-43
+ *   maxsim_rerank_counted / maxsim_topk_counted <- the same two steps on partly-live candidate rows (a doc shard's share of
+ *                          every list; the per-query distinct pids of colbert_ranker.py:212-229), scheduled from a device-built
+ *                          work list
  *   maxsim_shard_candidates <- no reference counterpart (its rerank is single-GPU, colbert_ranker.py:154): the
  *                          per-rank candidate filter of the doc-sharded path
  *
@@ -39,8 +42,9 @@
 extern "C" {
 #endif
 
-#define MAXSIM_VERSION 111 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
-                              maxsim_shard_candidates, maxsim_build_doc_table; 111: maxsim_score_dense_kernel */
+#define MAXSIM_VERSION 120 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
+                              maxsim_shard_candidates, maxsim_build_doc_table; 111: maxsim_score_dense_kernel;
+                              120: counted candidate rows (maxsim_rerank_counted, maxsim_topk_counted) */
 
 /* element types of Q / D / index */
 #define MAXSIM_F32 0
@@ -246,6 +250,29 @@ int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype,
  */
 int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64_t lo, int64_t hi,
                             int64_t* out_local, int64_t* out_global, int32_t* out_count, void* stream);
+
+/*
+ * Counted candidate rows.  A candidate matrix whose rows are only partly live -- one rank's share of a doc-sharded step
+ * (maxsim_shard_candidates: about 1/N of every row), the distinct pids of an ANN search (maxsim_embedding_ids_to_pids) --
+ * comes with a per-row live count in DEVICE memory.  Precondition for both entry points below: the live entries of row q
+ * are its first cand_count[q] slots and every slot after them holds a negative pid (what those two functions write).
+ * Results are then identical to maxsim_rerank_ex / maxsim_topk on the same matrices; what changes is the schedule:
+ *
+ * maxsim_rerank_counted: for h == 128 (any index dtype, docs longer than 24 tokens on average) the device builds a dense
+ *   list of wave-sized work items from the counts (two small kernels: a scan and a fill, which also writes the -inf
+ *   tail of `scores`) and the streaming kernel runs as a fixed grid whose waves walk that list -- no host
+ *   synchronisation to size the launch, no all-padding workgroups, every wave of every workgroup busy.  One rank's share
+ *   of an 8-way sharded step then costs what the same docs cost as dense rows.  Other shapes take maxsim_rerank_ex's path.
+ *   worklist: 16-byte aligned device scratch of maxsim_worklist_bytes(nq, ncand) bytes (contents need not survive the
+ *   call; NULL or too small = maxsim_rerank_ex's path).  ncand < 2^24 for the list form.
+ * maxsim_topk_counted: maxsim_topk that ranks the live slots only (ncand <= 2048; longer rows ignore the counts).
+ */
+int64_t maxsim_worklist_bytes(int nq, int ncand);
+int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
+                          const uint8_t* q_mask, const int64_t* cand_pids, const int32_t* cand_count, int nq, int ncand,
+                          int Lq, float* scores, void* worklist, int64_t worklist_bytes, void* stream);
+int maxsim_topk_counted(const float* scores, const int64_t* pids, const int32_t* counts, int nq, int ncand, int k,
+                        float* out_scores, int64_t* out_pids, void* stream);
 
 #ifdef __cplusplus
 }

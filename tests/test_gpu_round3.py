@@ -1,0 +1,148 @@
+"""GPU parity tests added in round 3: counted candidate rows (the device-built dense work list behind the doc-sharded
+step and ANN pid lists), reference-faithful failure modes of rank_forward, the 768-dim ragged fp16 deployment shape.
+Tolerances as in test_gpu_parity.py: fp32 |d| <= 1e-4, 16-bit inputs |d| <= 1e-3."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ATOL32 = 1e-4
+ATOL16 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import colbert_amd
+    return colbert_amd
+
+
+def nrm(gen, *shape):
+    return F.normalize(torch.randn(*shape, generator=gen), dim=-1)
+
+
+def _counted_rows(gen, nq, ncand, ndocs, counts):
+    """Rows as maxsim_shard_candidates / maxsim_embedding_ids_to_pids write them: counts[q] live pids first, then -1."""
+    cand = torch.full((nq, ncand), -1, dtype=torch.int64)
+    for q in range(nq):
+        c = int(counts[q])
+        cand[q, :c] = torch.randint(0, ndocs, (c,), generator=gen)
+    return cand
+
+
+# ------------------------------------------------------------------------------------------------------
+# counted rows: maxsim_rerank_counted / maxsim_topk_counted == maxsim_rerank_ex / maxsim_topk, bit for bit
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cfg", [
+    dict(dtype=torch.float32, mode="exact", Lq=32, lo=30, hi=180, nq=37, ncand=300),
+    dict(dtype=torch.float32, mode="exact", Lq=12, lo=30, hi=180, nq=16, ncand=200),     # one 16-column block
+    dict(dtype=torch.float32, mode="exact", Lq=70, lo=40, hi=120, nq=9, ncand=90),       # three query slices (accumulating passes)
+    dict(dtype=torch.float32, mode="bf16x3", Lq=32, lo=30, hi=180, nq=12, ncand=150),
+    dict(dtype=torch.float32, mode="fast", Lq=32, lo=30, hi=180, nq=12, ncand=150),
+    dict(dtype=torch.float16, mode="exact", Lq=32, lo=25, hi=180, nq=20, ncand=260),     # the reference's storage dtype
+    dict(dtype=torch.bfloat16, mode="exact", Lq=32, lo=25, hi=180, nq=10, ncand=128),
+    dict(dtype=torch.float32, mode="exact", Lq=32, lo=1, hi=12, nq=8, ncand=100),        # short docs: static grid fallback
+    dict(dtype=torch.float16, mode="exact", Lq=32, lo=10, hi=60, nq=6, ncand=70, h=768), # wide rows: static grid fallback
+], ids=lambda c: f"{str(c['dtype']).split('.')[-1]}-{c['mode']}-Lq{c['Lq']}-h{c.get('h', 128)}-{c['lo']}_{c['hi']}")
+def test_counted_rows_equal_full_width_rows(ca, cfg):
+    gen = torch.Generator().manual_seed(31)
+    h, ndocs, nq, ncand = cfg.get("h", 128), 500, cfg["nq"], cfg["ncand"]
+    doclens = torch.randint(cfg["lo"], cfg["hi"] + 1, (ndocs,), generator=gen).tolist()
+    doclens[7] = 0                                                                       # an empty doc scores 0
+    emb = nrm(gen, sum(doclens), h).to(cfg["dtype"])
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=cfg["dtype"], fp32_mode=cfg["mode"])
+    counts = torch.randint(0, ncand + 1, (nq,), generator=gen)
+    counts[0], counts[1], counts[2] = 0, ncand, 1                                        # empty row, full row, one doc
+    cand = _counted_rows(gen, nq, ncand, ndocs, counts)
+    cand[1, 3] = 7                                                                       # the empty doc
+    cand[1, 5] = ndocs + 9                                                               # an out-of-range pid INSIDE the live part: -inf
+    Q = nrm(gen, nq, cfg["Lq"], h)
+    qm = (torch.rand(nq, cfg["Lq"], generator=gen) > 0.2).long()
+    qm[:, 0] = 1
+    for kw in (dict(), dict(q_mask=qm)):
+        full = r.score_candidates(Q, cand.cuda(), **kw)
+        cnt = r.score_candidates(Q, cand.cuda(), cand_count=counts.cuda(), **kw)
+        assert torch.equal(full.cpu(), cnt.cpu())                                        # incl. the -inf tails
+        assert bool(torch.isinf(cnt[0]).all()) and float(cnt[1, 3]) == 0.0 and float(cnt[1, 5]) == float("-inf")
+    for k in (1, 10, ncand):
+        p0, s0 = r.topk(full, cand.cuda(), k)
+        p1, s1 = r.topk(cnt, cand.cuda(), k, counts.cuda())
+        assert torch.equal(s0.cpu(), s1.cpu()) and torch.equal(p0.cpu(), p1.cpu())
+
+
+def test_counted_rows_small_and_large_launches(ca):
+    """The builder picks the docs per wave item ON THE DEVICE from the number of live candidates: a launch with few of
+    them gets shorter items (more waves), one with many the ~1.4 k-token streams.  Both ends against the static grid."""
+    gen = torch.Generator().manual_seed(5)
+    ndocs, h = 3000, 128
+    doclens = torch.randint(100, 181, (ndocs,), generator=gen).tolist()
+    emb = nrm(gen, sum(doclens), h)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=torch.float32)
+    for nq, ncand, mean in ((1, 1000, 1000), (3, 64, 5), (300, 400, 50), (64, 1000, 125)):
+        counts = torch.randint(max(0, mean - mean // 4), min(ncand, mean + mean // 4) + 1, (nq,), generator=gen)
+        cand = _counted_rows(gen, nq, ncand, ndocs, counts)
+        Q = nrm(gen, nq, 32, h)
+        full = r.score_candidates(Q, cand.cuda())
+        cnt = r.score_candidates(Q, cand.cuda(), cand_count=counts.cuda())
+        assert torch.equal(full.cpu(), cnt.cpu()), (nq, ncand, mean)
+
+
+def test_worklist_layout(ca):
+    """The work list itself: items cover every live slot exactly once, in row order, with at most D docs each, and the
+    header agrees (maxsim_worklist.h).  Read back through the C ABI's scratch buffer."""
+    gen = torch.Generator().manual_seed(9)
+    ndocs, h, nq, ncand = 2000, 128, 50, 333
+    doclens = [150] * ndocs
+    emb = nrm(gen, sum(doclens), h)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=torch.float32)
+    counts = torch.randint(0, ncand + 1, (nq,), generator=gen).to(torch.int32)
+    cand = _counted_rows(gen, nq, ncand, ndocs, counts).cuda()
+    Q = nrm(gen, nq, 32, h).cuda()
+    lib = ca._lib.lib
+    nbytes = int(lib.maxsim_worklist_bytes(nq, ncand))
+    wl = torch.zeros(nbytes // 4, dtype=torch.int32, device="cuda")
+    scores = torch.empty(nq, ncand, device="cuda")
+    cc = counts.cuda()
+    rc = lib.maxsim_rerank_counted(ctypes.byref(r._iv), Q.data_ptr(), 0, None, None, cand.data_ptr(), cc.data_ptr(), nq, ncand,
+                                   32, scores.data_ptr(), wl.data_ptr(), nbytes, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    w = wl.cpu()
+    total, D, live = int(w[0]), int(w[1]), int(w[2])
+    assert live == int(counts.sum()) and 1 <= D <= 64
+    starts = w[16:16 + nq + 1].tolist()
+    off = (16 + nq + 1 + 3) & ~3
+    items = w[off:off + 2 * total].view(total, 2)
+    assert starts[0] == 0 and starts[-1] == total
+    for q in range(nq):
+        c = int(counts[q])
+        mine = items[starts[q]:starts[q + 1]]
+        assert len(mine) == (c + D - 1) // D
+        pos = 0
+        for qq, packed in mine.tolist():
+            b, n = packed & 0xffffff, packed >> 24
+            assert qq == q and b == pos and 1 <= n <= D
+            pos += n
+        assert pos == c
+
+
+def test_sharded_local_topk_uses_counted_rows(ca):
+    """ShardedRanker.local_topk (shard filter -> counted rerank -> counted top-k) == the same steps on full-width rows."""
+    from colbert_amd.sharded import ShardedRanker, shard_candidates
+    gen = torch.Generator().manual_seed(13)
+    ndocs, h = 1500, 128
+    doclens = torch.randint(60, 181, (ndocs,), generator=gen).tolist()
+    emb = nrm(gen, sum(doclens), h).half()
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=torch.float16)
+    lo, hi = 3 * ndocs, 4 * ndocs                                        # rank 3 of 8
+    cand = torch.randint(0, 8 * ndocs, (40, 1000), generator=gen).cuda()
+    Q = nrm(gen, 40, 32, h)
+    sh = ShardedRanker(r, lo, hi)
+    p1, s1 = sh.local_topk(Q, cand, 100)
+    loc, gp = shard_candidates(cand, lo, hi)
+    p0, s0 = r.topk(r.score_candidates(Q, loc), gp, 100)
+    assert torch.equal(p0.cpu(), p1.cpu()) and torch.equal(s0.cpu(), s1.cpu())
+    assert int((p1 >= 0).sum()) > 0 and bool(((p1 < 0) | ((p1 >= lo) & (p1 < hi))).all())
