@@ -15,12 +15,21 @@ are real HBM reads.
 N > 1 (configs[2]: doc-sharded, weak scaling): every rank holds its own 1M-doc shard (pid range [rank*1M, (rank+1)*1M)),
 the batch is 256*N queries, every query has 1000 candidates drawn uniformly over ALL N*1M pids (about 1000/N +- sqrt
 per shard) and the same global lists are handed to every rank.  A step is the shipped sharded path:
-ShardedRanker.local_topk (maxsim_shard_candidates -> fused rerank -> local top-100 with global pids) ->
-exchange_async (ONE RCCL all_gather + per-query merge, on a side stream, overlapping the next batch's rerank).
-value = queries of all ranks / max-over-ranks time.  A second, labelled measurement ("stratified") runs the same path
-on lists with exactly 1000/N candidates per shard.
+ShardedRanker.local_topk (maxsim_shard_candidates -> counted rerank from a device-built work list -> local top-100 with
+global pids) -> exchange_async (ONE RCCL all_gather + per-query merge, on a side stream, overlapping the next batch's
+rerank).  value = queries of all ranks / max-over-ranks time.  A second, labelled measurement ("stratified") runs the same
+path on lists with exactly 1000/N candidates per shard.
+
+The default N = 1 run also reports, in the same JSON line and each driver-timed in this process:
+  sharded_share   one rank's share of an N = 2 / 4 / 8 step on this GPU (256*N queries, ~1000/N live candidates per row):
+                  what every rank of that job does before the exchange -- the expected weak-scaling curve's compute side
+  other_workloads BASELINE configs[3], [4], the reference's fp16 storage dtype, ragged doclens, the reference's default
+                  deployment shape (dim 768 fp16 ragged) and the opt-in bf16x3 contraction of the fp32 index
+  single_query    the reference's online call (one rank_forward), training_form (the operator's second caller),
+  cpu_baseline    the oracle on the host cores (never the product path), roofline.read_ceiling (measured on this box).
 """
 import argparse
+import ctypes
 import json
 import os
 import socket
@@ -35,20 +44,23 @@ import torch.nn.functional as F
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-LQ, LD, H, NQ, NCAND, TOPK = 32, 180, 128, 256, 1000, 100
+NQ, NCAND, TOPK = 256, 1000, 100
 
-# extra workloads (reported next to the headline one, never as `value` of the default run):
+# ragged = (mean, sd, lo, hi) of a clipped normal; None = every doc has `ld` tokens
 #   ragged : doclens ~ clipped N(120, 40) in [8, 180]     -- exercises packed tiles + 0-floor buckets
 #   c4     : multi-view, 8 viewer tokens per doc, Lq = 8 (dense.yaml q_view = d_view)
 #   c5     : bf16, dim 768, 256 tokens per doc, 200k docs
+#   dep768 : the reference's default deployment (proj_conf/dense.yaml:6-8 dim 768, doc_maxlen 384; encoder.py:175 fp16 index):
+#            ragged doclens ~ clipped N(200, 80) in [8, 384]
 WORKLOADS = {
-    "c2": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=False, dtype="fp32"),
-    "ragged": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=True, dtype="fp32"),
-    "c4": dict(lq=8, ld=8, h=128, ndocs=4_000_000, ragged=False, dtype="fp32"),
-    "c5": dict(lq=32, ld=256, h=768, ndocs=200_000, ragged=False, dtype="bf16", qdtype="bf16"),
+    "c2": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=None, dtype="fp32"),
+    "ragged": dict(lq=32, ld=180, h=128, ndocs=1_000_000, ragged=(120, 40, 8, 180), dtype="fp32"),
+    "c4": dict(lq=8, ld=8, h=128, ndocs=4_000_000, ragged=None, dtype="fp32"),
+    "c5": dict(lq=32, ld=256, h=768, ndocs=200_000, ragged=None, dtype="bf16", qdtype="bf16"),
+    "dep768": dict(lq=32, ld=384, h=768, ndocs=200_000, ragged=(200, 80, 8, 384), dtype="fp16"),
 }
 HBM_PEAK_GBS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
-HBM_ACHIEVABLE_GBS = 6300.0  # what a read-only stream reaches on this part (same guide; the kernel's DMA-only ablation agrees)
+TDT = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}
 
 
 def build_index(ntok, h, dev, seed, dtype):
@@ -60,6 +72,14 @@ def build_index(ntok, h, dev, seed, dtype):
         e = min(s + chunk, ntok)
         idx[s:e] = F.normalize(torch.randn(e - s, h, generator=gen, device=dev), dim=-1).to(dtype)
     return idx
+
+
+def make_doclens(wl, ndocs, ld, rank=0):
+    if wl["ragged"] is None:
+        return [ld] * ndocs                         # uniform docs: strides = [LD], one bucket, no padding floor
+    mean, sd, lo, hi = wl["ragged"]
+    g = torch.Generator().manual_seed(99 + rank)
+    return (torch.randn(ndocs, generator=g) * sd + mean).round().clamp(lo, min(hi, ld)).long().tolist()
 
 
 def host_cores():
@@ -74,10 +94,136 @@ def host_cores():
     return n
 
 
+def kernel_name(h, lq):
+    if lq > 32 and h != 128:
+        return "k_maxsim_generic"
+    return "k_maxsim_stream" if h == 128 else "k_maxsim_stream_bigh" if 16 <= h <= 1024 else "k_maxsim_generic"
+
+
+def pmc_lookup(workload, index_dtype, fp32_mode, suffix=""):
+    """HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
+    MI355X_MICROARCH.md prescribes; summaries committed under profiles/ by tools/summarize_profile.py).  These fields are
+    REPLAYED from that file (named in pmc_source), not measured in this run."""
+    mode_tag = "" if (index_dtype != "fp32" or fp32_mode == "exact") else fp32_mode
+    dt_tag = "f32" if index_dtype == "fp32" else index_dtype
+    for tag in ("r03", "r02", "r01"):
+        pmc = os.path.join(ROOT, "profiles", f"{tag}_{workload}{suffix}_{dt_tag}{mode_tag}_pmc.json")
+        if not os.path.exists(pmc):
+            continue
+        try:
+            for k, v in json.load(open(pmc)).items():
+                if "k_maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
+                    traffic = int(v["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] + v.get("hbm_write_bytes_per_launch(WRITE_SIZE*1024)", 0))
+                    return traffic, v.get("mfma_util(SQ_VALU_MFMA_BUSY_CYCLES/1024 / (GRBM_GUI_ACTIVE/8))"), os.path.relpath(pmc, ROOT)
+        except (OSError, ValueError):
+            pass
+    return None, None, None
+
+
+def timed_steps(step, warmup, steps, barrier=None):
+    """W untimed warm-up steps, then EXACTLY K timed steps between (barrier +) synchronize on both sides.  `step(i)`
+    issues step i and returns a handle (or None); a step's handle is resolved while the next step is in flight."""
+    def finish(h):
+        return h.result() if hasattr(h, "result") else h
+    for i in range(warmup):
+        finish(step(i))
+    if barrier:
+        barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pending = None
+    for i in range(warmup, warmup + steps):
+        h = step(i)
+        if pending is not None:
+            finish(pending)
+        pending = h
+    finish(pending)
+    torch.cuda.synchronize()
+    if barrier:
+        barrier()
+        torch.cuda.synchronize()
+    return time.perf_counter() - t0
+
+
+def live_tokens(ranker, batches, lo, hi, warmup, steps):
+    """Mean (candidate tokens, candidate docs) of the timed steps that fall in this rank's pid range."""
+    tot, n = 0, 0
+    for i in range(warmup, warmup + steps):
+        c = batches[i % batches.size(0)]
+        loc = c[(c >= lo) & (c < hi)] - lo
+        tot += int(ranker.d_doclens[loc].sum().item())
+        n += loc.numel()
+    return tot / steps, n / steps
+
+
+def algorithmic_bytes(cand_tokens, docs, nq, lq, h, esize, qsize):
+    """doc tokens read once + Q + pid (8) + offset/len (12) + score (4) per candidate."""
+    return int(cand_tokens * h * esize + nq * lq * h * qsize + docs * (8 + 12 + 4))
+
+
+def bench_rows(ranker, Q, cands, warmup, steps, k, sharded=None):
+    """One GPU, no exchange: K steps of rerank + top-k over `cands[i]`.  sharded = a ShardedRanker: the step is its
+    local_topk (shard filter + counted rerank + counted top-k) on GLOBAL candidate lists.  Returns (wall s, kernel ms):
+    kernel ms = HIP events around the rerank launch(es) on the launch stream (torch's current stream)."""
+    total = warmup + steps
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(2)] for _ in range(total)]
+    cur = {"i": 0}
+    inner = ranker.score_candidates
+
+    def timed_score(Qb, cand_local, **kw):
+        e0, e1 = ev[cur["i"]]
+        e0.record()
+        out = inner(Qb, cand_local, **kw)
+        e1.record()
+        return out
+
+    if sharded is not None:
+        sharded.score_fn = timed_score
+
+    def step(i):
+        cur["i"] = i
+        c = cands[i % cands.size(0)]
+        if sharded is not None:
+            return sharded.local_topk(Q, c, k)
+        return ranker.topk(timed_score(Q, c), c, min(k, c.size(1)))
+
+    el = timed_steps(step, warmup, steps)
+    kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(warmup, total)) / steps
+    return el, kern_ms
+
+
+def read_ceiling(buf):
+    """The read rate this box's memory system delivers to the kernels' own fetch pattern (non-temporal LDS-DMA into
+    per-wave rings, nothing consumed): maxsim_hbm_read_probe over the first 16 GiB of `buf`, best of its three ring
+    shapes, HIP events around 3 launches each (SURVEY 8d asks for a measured ceiling next to the spec peak)."""
+    from colbert_amd import _lib
+    nbytes = min(buf.numel() * buf.element_size(), 16 << 30)
+    st = torch.cuda.current_stream().cuda_stream
+    got = ctypes.c_int64(0)
+    best, per_variant = 0.0, {}
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for variant, name in ((0, "1x16KiB"), (1, "2x8KiB"), (2, "2x16KiB")):
+        rc = _lib.lib.maxsim_hbm_read_probe(buf.data_ptr(), nbytes, variant, ctypes.addressof(got), st)
+        assert rc == 0, rc
+        e0.record()
+        for _ in range(3):
+            _lib.lib.maxsim_hbm_read_probe(buf.data_ptr(), nbytes, variant, None, st)
+        e1.record()
+        e1.synchronize()
+        gbs = got.value * 3 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        per_variant[name] = round(gbs, 1)
+        best = max(best, gbs)
+    return {"GBps": round(best, 1), "by_ring_shape": per_variant, "bytes_per_launch": got.value,
+            "how": "maxsim_hbm_read_probe: every wave streams 512 KiB through nt LDS-DMA into its LDS ring, nothing consumed; "
+                   "3 launches between two HIP events per shape"}
+
+
 def cpu_baseline(seconds=12.0):
     """The oracle restatement of the reference's score() (BaseModel.py:39-46) on the host cores: the reference's
-    unit of work, 1 query x 1000 docs per call (colbert_ranker.py:111-112), fp32."""
-    from oracle.maxsim_oracle import ref_score
+    unit of work, 1 query x 1000 docs per call (colbert_ranker.py:111-112), fp32; plus C1 (1 x 10, BASELINE configs[0])
+    and the whole reference-shaped rank_forward."""
+    from oracle.maxsim_oracle import RefRanker, ref_score
+    LQ, LD, H = 32, 180, 128
     cores = host_cores()
     torch.set_num_threads(cores)
     gen = torch.Generator().manual_seed(0)
@@ -95,9 +241,19 @@ def cpu_baseline(seconds=12.0):
             break
     out = {"value": round(n / el, 3), "unit": "queries/s", "cores": cores, "kind": "port",
            "sample": f"{n} calls of 1 query x {NCAND} docs x ({LQ}x{LD}) tokens dim {H} fp32, torch CPU, {cores} threads"}
+    # C1 (BASELINE.json configs[0]): 1 query x 10 docs, the reference's own CPU-runnable case
+    D10, dm10 = D[:10].contiguous(), dm[:10].contiguous()
+    for _ in range(5):
+        ref_score(Q, D10, qm, dm10)
+    m, t1 = 0, time.perf_counter()
+    while time.perf_counter() - t1 < 2.0 or m < 20:
+        ref_score(Q, D10, qm, dm10)
+        m += 1
+    el1 = time.perf_counter() - t1
+    out["c1"] = {"value": round(m / el1, 2), "unit": "queries/s", "ms_per_call": round(el1 / m * 1e3, 4),
+                 "sample": f"{m} calls of 1 query x 10 docs x ({LQ}x{LD}) tokens dim {H} fp32 (C1), torch CPU, {cores} threads"}
     # the whole reference-shaped rank_forward (colbert_ranker.py:75-137: CPU gather from the fp16 strided view, cast,
     # mask, score, sort) on a small host-resident index -- what one query costs the reference before PCIe
-    from oracle.maxsim_oracle import RefRanker
     nd = 4000
     part = F.normalize(torch.randn(nd * LD, H, generator=gen), dim=-1).half()
     rr = RefRanker([part], [[LD] * nd], dim=H)
@@ -110,6 +266,92 @@ def cpu_baseline(seconds=12.0):
         m += 1
     out["rank_forward"] = {"value": round(m / (time.perf_counter() - t1), 3), "unit": "queries/s",
                            "sample": f"{m} calls of the restated rank_forward, 1 query x {NCAND} of {nd} docs, fp16 CPU index"}
+    return out
+
+
+def roofline_entry(kern_ms, alg_bytes, cand_tokens, lq, h, workload, index_dtype, fp32_mode, default_shape, suffix=""):
+    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    traffic = mfma_busy = pmc_source = None
+    if default_shape:
+        traffic, mfma_busy, pmc_source = pmc_lookup(workload, index_dtype, fp32_mode, suffix)
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "pmc_source": pmc_source,
+            "kernel": kernel_name(h, lq), "kernel_ms": round(kern_ms, 4), "algorithmic_bytes_per_launch": alg_bytes,
+            # matrix-pipe view of the same launch (PMC pass, profiles/): busy fraction of the MFMA pipe
+            "mfma_busy_frac": None if mfma_busy is None else round(mfma_busy, 3),
+            "mfma_tflops": round(2.0 * lq * h * cand_tokens / (kern_ms * 1e-3) / 1e12, 1)}
+
+
+def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32_mode="exact", reuse=None, label=None):
+    """One more BASELINE / deployment workload on this GPU, 256 queries x 1000 candidates per step, the index built once
+    (or `reuse` = (idx, doclens) of a workload that is still resident).  Not `value`: a labelled entry of other_workloads."""
+    wl = WORKLOADS[name]
+    lq, ld, h = wl["lq"], wl["ld"], wl["h"]
+    index_dtype = index_dtype or wl["dtype"]
+    dtype = TDT[index_dtype]
+    esize = torch.empty(0, dtype=dtype).element_size()
+    if reuse is None:
+        doclens = make_doclens(wl, wl["ndocs"], ld)
+        idx = build_index(sum(doclens), h, dev, 1234, dtype)
+    else:
+        idx, doclens = reuse
+    ranker = colbert_amd.ColbertRanker.from_device_tensor(idx, doclens, fp32_mode=fp32_mode)
+    gq = torch.Generator(device=dev).manual_seed(1)
+    Q = F.normalize(torch.randn(NQ, lq, h, generator=gq, device=dev), dim=-1).to(TDT[wl.get("qdtype", "fp32")])
+    total = warmup + steps
+    gc = torch.Generator(device=dev).manual_seed(2)
+    cands = torch.randint(0, len(doclens), (total, NQ, NCAND), generator=gc, device=dev, dtype=torch.int64)
+    el, kern_ms = bench_rows(ranker, Q, cands, warmup, steps, TOPK)
+    cand_tokens, docs = live_tokens(ranker, cands, 0, len(doclens), warmup, steps)
+    alg = algorithmic_bytes(cand_tokens, docs, NQ, lq, h, esize, Q.element_size())
+    rf = roofline_entry(kern_ms, alg, cand_tokens, lq, h, name, index_dtype, fp32_mode, True)
+    shape = f"{lq}x{ld}" if wl["ragged"] is None else f"{lq}x~{wl['ragged'][0]} ({wl['ragged'][2]}..{wl['ragged'][3]} ragged)"
+    out = {"workload": label or name, "shape": f"{NQ} queries x {NCAND} candidates, {shape} tokens, dim {h}, {index_dtype} index of "
+                                               f"{len(doclens)} docs" + (f", fp32_mode {fp32_mode}" if fp32_mode != "exact" else ""),
+           "steps": steps, "warmup": warmup, "queries_per_s": round(NQ * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4)}
+    out.update({k: rf[k] for k in ("kernel", "kernel_ms", "algorithmic_bytes_per_launch", "achieved", "frac", "traffic",
+                                   "pmc_source", "mfma_busy_frac", "mfma_tflops")})
+    return out, (idx, doclens)
+
+
+def sharded_share(colbert_amd, ranker, ndocs, dev, lq, h, esize, steps, warmup, Q1, cands1):
+    """One rank's share of an N-way doc-sharded step, N = 2, 4, 8, on THIS GPU: 256*N queries whose 1000 candidates are
+    drawn uniformly over all N shards, through the shipped per-rank path (ShardedRanker.local_topk: shard filter ->
+    counted rerank from the device-built work list -> counted top-100 with global pids).  Everything a rank does per step
+    except the all_gather + merge; the docs it reads are ~256 x 1000, as at N = 1.  The chip's clock drifts by a few
+    percent with what ran before, so every share is bracketed by two short runs of the N = 1 step (256 dense rows, the
+    headline workload) and compared with their mean."""
+    from colbert_amd.sharded import ShardedRanker
+    out = {}
+
+    def n1():
+        return bench_rows(ranker, Q1, cands1, warmup, steps, TOPK)[1]
+    before = n1()
+    for of in (2, 4, 8):
+        job_rank = min(3, of - 1)
+        lo, hi = job_rank * ndocs, (job_rank + 1) * ndocs
+        sh = ShardedRanker(ranker, lo, hi)
+        nq = NQ * of
+        gq = torch.Generator(device=dev).manual_seed(1)
+        Q = F.normalize(torch.randn(nq, lq, h, generator=gq, device=dev), dim=-1)
+        nb = min(warmup + steps, 6)
+        gc = torch.Generator(device=dev).manual_seed(2)
+        cands = torch.randint(0, of * ndocs, (nb, nq, NCAND), generator=gc, device=dev, dtype=torch.int64)
+        el, kern_ms = bench_rows(ranker, Q, cands, warmup, steps, TOPK, sharded=sh)
+        after = n1()
+        n1_kernel_ms, before = 0.5 * (before + after), after
+        cand_tokens, docs = live_tokens(ranker, cands, lo, hi, warmup, steps)
+        alg = algorithmic_bytes(cand_tokens, docs, nq, lq, h, esize, 4)
+        out[str(of)] = {"kernel_ms": round(kern_ms, 4), "step_ms": round(el / steps * 1e3, 4),
+                        "frac": round(alg / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "algorithmic_bytes_per_launch": alg, "local_candidates_per_query": round(docs / nq, 2),
+                        "queries_per_step": nq, "simulated_rank": job_rank,
+                        # same docs per step as N = 1: the ratio is what sharding costs a rank before the exchange
+                        "n1_kernel_ms_bracketing": round(n1_kernel_ms, 4), "kernel_ms_vs_n1": round(kern_ms / n1_kernel_ms, 4)}
+        del cands, Q, sh
+    out["how"] = ("ShardedRanker.local_topk on one GPU, rank 'simulated_rank' of N; kernel_ms = HIP events around the counted rerank "
+                  "(work-list scan + fill + stream kernel); step_ms = wall per step incl. the shard filter and the top-k; no "
+                  f"exchange; {steps} steps after {warmup} warm-up")
     return out
 
 
@@ -131,7 +373,10 @@ def main():
     ap.add_argument("--ncand", type=int, default=0,
                     help="candidates per query on each GPU (0 = 1000 / N; diagnostic: --nq 2048 --ncand 125 is one rank's share of N = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true",
-                    help="skip the host-side legs (cpu_baseline and the single-query latency probe): profiling runs")
+                    help="skip everything but the headline measurement (cpu_baseline, single_query, training_form, sharded_share, "
+                         "other_workloads, read ceiling): profiling runs")
+    ap.add_argument("--no-extras", action="store_true", help="skip sharded_share and other_workloads only")
+    ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of every sharded_share / other_workloads entry")
     ap.add_argument("--as-rank", type=int, default=-1,
                     help="diagnostic, with --gpus 1: run ONE rank's share of an --of N job on this GPU (256*N queries, candidates "
                          "drawn over all N shards, shard filter + rerank + local top-k; no exchange unless --force-dist)")
@@ -179,15 +424,10 @@ def main():
     wl = WORKLOADS[args.workload]
     LQ, LD, H = (args.lq or wl["lq"]), (args.ld or wl["ld"]), wl["h"]
     args.index_dtype = args.index_dtype or wl["dtype"]
-    dtype = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[args.index_dtype]
+    dtype = TDT[args.index_dtype]
     esize = torch.empty(0, dtype=dtype).element_size()
     ndocs = args.ndocs or wl["ndocs"]
-    if wl["ragged"]:
-        g = torch.Generator().manual_seed(99 + rank)
-        doclens = (torch.randn(ndocs, generator=g) * 40 + 120).round().clamp(8, LD).long().tolist()
-    else:
-        # uniform docs: strides = [LD], one bucket, no padding floor
-        doclens = [LD] * ndocs
+    doclens = make_doclens(wl, ndocs, LD, rank)
     ntok = sum(doclens)
     idx = build_index(ntok, H, dev, 1234 + rank, dtype)
     ranker = colbert_amd.ColbertRanker.from_device_tensor(idx, doclens, fp32_mode=args.fp32_mode)
@@ -203,7 +443,7 @@ def main():
     gq = torch.Generator(device=dev).manual_seed(1)            # same queries on every rank
     Q = F.normalize(torch.randn(nq, LQ, H, generator=gq, device=dev), dim=-1)
     q_dtype = args.q_dtype or wl.get("qdtype", "fp32")
-    Q = Q.to({"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[q_dtype])
+    Q = Q.to(TDT[q_dtype])
     # candidate lists: GLOBAL pids, the same on every rank (same seed); a ring of NB distinct batches (one batch of docs
     # is >= 23 GB of tokens >> the 256 MB Infinity Cache, so re-using a batch NB steps later still reads HBM)
     NB = total if job_world == 1 else min(total, 8)
@@ -222,47 +462,36 @@ def main():
         return out
     sharded.score_fn = timed_score
 
-    def step(i, batches):
-        timed["i"] = i
-        cand_global = batches[i % batches.size(0)]
-        if world == 1 and not use_dist and not sim:
-            scores = timed_score(Q, cand_global)
-            return ranker.topk(scores, cand_global, min(TOPK, ncand_q))
-        # the shipped sharded path: shard filter -> rerank -> local top-k (global pids) ...
-        top_p, top_s = sharded.local_topk(Q, cand_global, TOPK)
-        # ... then the ONE exchange step (all_gather over xGMI) + the per-query merge on the side stream: batch i's
-        # exchange overlaps batch i+1's rerank kernel; every batch is complete before the timed region ends
-        if sim and not use_dist:
-            return top_p, top_s
-        h = sharded.exchange_async(top_p, top_s, TOPK)
-        if os.environ.get("MAXSIM_BENCH_NO_PIPELINE"):   # diagnostic: resolve the exchange before the next batch is issued
-            h.result()
-        return h
-
-    def finish(h):
-        return h.result() if hasattr(h, "result") else h
+    def make_step(batches):
+        def step(i):
+            timed["i"] = i
+            cand_global = batches[i % batches.size(0)]
+            if world == 1 and not use_dist and not sim:
+                scores = timed_score(Q, cand_global)
+                return ranker.topk(scores, cand_global, min(TOPK, ncand_q))
+            # the shipped sharded path: shard filter -> counted rerank -> local top-k (global pids) ...
+            top_p, top_s = sharded.local_topk(Q, cand_global, TOPK)
+            # ... then the ONE exchange step (all_gather over xGMI) + the per-query merge on the side stream: batch i's
+            # exchange overlaps batch i+1's rerank kernel; every batch is complete before the timed region ends
+            if sim and not use_dist:
+                return top_p, top_s
+            h = sharded.exchange_async(top_p, top_s, TOPK)
+            if os.environ.get("MAXSIM_BENCH_NO_PIPELINE"):   # diagnostic: resolve the exchange before the next batch is issued
+                h.result()
+            return h
+        return step
 
     def run(batches):
         """W warm-up steps, then exactly K timed steps between barrier + synchronize on both sides; max over ranks."""
-        for i in range(args.warmup):
-            finish(step(i, batches))
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        sharded.exchange_events = [] if use_dist else None
-        t0 = time.perf_counter()
-        pending = None
-        for i in range(args.warmup, total):
-            h = step(i, batches)
-            if pending is not None:
-                finish(pending)
-            pending = h
-        finish(pending)
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+        sharded.exchange_events = None
+
+        def barrier():
+            if use_dist:
+                dist.barrier()
+            # the exchange timing list starts with the timed region (first call = before, second = after)
+            if use_dist and sharded.exchange_events is None:
+                sharded.exchange_events = []
+        el = timed_steps(make_step(batches), args.warmup, args.steps, barrier)
         if use_dist:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             if one_gpu:
@@ -277,17 +506,8 @@ def main():
     el, kern_ms, xch_ms = run(cands)
 
     # algorithmic bytes of ONE rerank launch on this rank: doc tokens read once + Q + pid/offset/len + score
-    def local_tokens(batches):
-        tot, n = 0, 0
-        for i in range(args.warmup, total):
-            c = batches[i % batches.size(0)]
-            loc = c[(c >= lo) & (c < hi)] - lo
-            tot += int(ranker.d_doclens[loc].sum().item())
-            n += loc.numel()
-        return tot / args.steps, n / args.steps
-    cand_tokens, docs = local_tokens(cands)
-    alg_bytes = int(cand_tokens * H * esize + nq * LQ * H * Q.element_size() + docs * (8 + 12 + 4))
-    achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+    cand_tokens, docs = live_tokens(ranker, cands, lo, hi, args.warmup, args.steps)
+    alg_bytes = algorithmic_bytes(cand_tokens, docs, nq, LQ, H, esize, Q.element_size())
 
     # second, labelled measurement for N > 1: the same path on stratified lists (exactly 1000/N candidates per shard)
     strat = None
@@ -300,6 +520,7 @@ def main():
         s_el, s_kern, s_xch = run(sc)
         strat = {"value": round(nq * args.steps / s_el, 2), "ms_per_step": round(s_el / args.steps * 1e3, 4),
                  "kernel_ms_rank0": round(s_kern, 4), "candidates": f"exactly {per} per shard per query"}
+        del sc
 
     # per-rank figures (every rank contributes one row)
     per_rank = None
@@ -311,29 +532,13 @@ def main():
                     "exchange_merge_ms": [round(float(r[1]), 4) for r in rows],
                     "local_candidates_per_query": [round(float(r[2]), 2) for r in rows]}
 
-    # HBM bytes per launch from the PMC passes (separate rocprofv3 --pmc runs of this same command, corrected as
-    # MI355X_MICROARCH.md prescribes; summaries committed under profiles/ by tools/summarize_profile.py).  These two
-    # fields are REPLAYED from that file (named in pmc_source), not measured in this run.
-    traffic = mfma_busy = pmc_source = None
-    mode_tag = "" if (args.index_dtype != "fp32" or args.fp32_mode == "exact") else args.fp32_mode
-    dt_tag = "f32" if args.index_dtype == "fp32" else args.index_dtype
-    default_shape = world == 1 and ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand or args.ld or args.q_dtype)
-    for tag in ("r02", "r01"):
-        pmc = os.path.join(ROOT, "profiles", f"{tag}_{args.workload}_{dt_tag}{mode_tag}_pmc.json")
-        if not (default_shape and os.path.exists(pmc)):
-            continue
-        try:
-            for k, v in json.load(open(pmc)).items():
-                if "k_maxsim" in k and "hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)" in v:
-                    traffic = int(v["hbm_read_bytes_per_launch(2*FETCH_SIZE*1024)"] + v.get("hbm_write_bytes_per_launch(WRITE_SIZE*1024)", 0))
-                    mfma_busy = v.get("mfma_util(SQ_VALU_MFMA_BUSY_CYCLES/1024 / (GRBM_GUI_ACTIVE/8))")
-                    pmc_source = os.path.relpath(pmc, ROOT)
-        except (OSError, ValueError):
-            traffic = None
-        if traffic is not None:
-            break
+    default_shape = ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand or args.ld or args.q_dtype) and (world == 1)
+    suffix = f"_shard{job_world}" if sim else ""
+    rf = roofline_entry(kern_ms, alg_bytes, cand_tokens, LQ, H, args.workload, args.index_dtype, args.fp32_mode,
+                        default_shape, suffix)
 
     if rank == 0:
+        rag = wl["ragged"]
         res = {
             "metric": "queries/sec MaxSim rerank, 32q x 180d tokens, dim=128, 1000 docs/query" if args.workload == "c2"
                       else f"queries/sec MaxSim rerank, workload {args.workload}",
@@ -341,22 +546,14 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload.upper()}: {args.nq or NQ} queries/GPU x {ncand_q} candidates/query, {LQ}x"
-                                   f"{'~120 (8..180 ragged)' if wl['ragged'] else LD} tokens, dim {H}, "
+                                   f"{f'~{rag[0]} ({rag[2]}..{rag[3]} ragged)' if rag else LD} tokens, dim {H}, "
                                    f"{args.index_dtype} index of {ndocs} docs/GPU in HBM, fused rerank + top-{TOPK}"
                                    + (f", doc-sharded x{world}: candidates uniform over all {world * ndocs} pids, shard filter + "
                                       f"local top-{TOPK} + RCCL all_gather + merge" if world > 1 else "")
                                    + (f", SIMULATED rank {job_rank} of {job_world} (one rank's share of the job, no exchange)" if sim else ""),
                        "queries_per_step": nq, "candidates_per_query": ncand_q, "docs_per_gpu": ndocs,
                        "index_dtype": args.index_dtype, "q_dtype": q_dtype, "fp32_mode": args.fp32_mode, "parallelism": f"doc-shard x{world}"},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4),
-                         "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4), "achievable_peak": HBM_ACHIEVABLE_GBS,
-                         "traffic": traffic, "pmc_source": pmc_source,
-                         "kernel": ("k_maxsim_stream" if H == 128 else "k_maxsim_stream_bigh" if H % 128 == 0 and H <= 1024 else "k_maxsim_generic") if LQ <= 32 else "k_maxsim_generic", "kernel_ms": round(kern_ms, 4),
-                         "algorithmic_bytes_per_launch": alg_bytes,
-                         # matrix-pipe view of the same launch (PMC pass, profiles/): busy fraction of the MFMA pipe
-                         "mfma_busy_frac": None if mfma_busy is None else round(mfma_busy, 3),
-                         "mfma_tflops": round(2.0 * LQ * H * cand_tokens / (kern_ms * 1e-3) / 1e12, 1)},
+            "roofline": rf,
         }
         if use_dist:
             res["n_ranks_seen"] = dist.get_world_size()
@@ -364,11 +561,40 @@ def main():
             res["per_rank"] = per_rank
         if strat is not None:
             res["stratified"] = strat
-        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
+        full = world == 1 and args.workload == "c2" and not args.no_cpu_baseline and not sim and default_shape
+        if full:
+            ceil = read_ceiling(idx)
+            rf["read_ceiling"] = ceil
+            rf["frac_of_read_ceiling"] = round(rf["achieved"] / ceil["GBps"], 4)
             res["single_query"] = single_query_probe(ranker, Q, cands, H, LQ, esize)
-        if world == 1 and args.workload == "c2" and not args.no_cpu_baseline:
+        if full and not args.no_extras:
+            xs, xw = args.extra_steps, 3
+            res["sharded_share"] = sharded_share(colbert_amd, ranker, ndocs, dev, LQ, H, esize, xs, xw, Q, cands)
+            others = []
+            # the opt-in 3 x bf16 contraction of the SAME fp32 index (fp32-class accuracy, not an exact fmaf chain: labelled extra)
+            o, keep = extra_workload(colbert_amd, "c2", dev, xs, xw, fp32_mode="bf16x3", reuse=(idx, doclens), label="c2 fp32 index, fp32_mode=bf16x3 (opt-in)")
+            o["accuracy"] = "fp32-class (tests/test_gpu_parity.py::test_fp32_bf16x3_mode_is_fp32_accurate); default stays the exact fmaf chain"
+            others.append(o)
+            # the 92 GB headline index leaves HBM before the next ones are built (every name that reaches it is cleared:
+            # the closures above share these cells)
+            ranker = sharded = idx = cands = score_inner = keep = None
+            torch.cuda.empty_cache()
+            for name, kw, label in (("c2", dict(index_dtype="fp16"), "c2 with the reference's fp16 index (colbert_ranker.py:62)"),
+                                    ("ragged", {}, "ragged fp32 (doclens N(120,40) in 8..180)"),
+                                    ("c4", {}, "C4 multi-view: 8 x 8 tokens (BASELINE configs[3])"),
+                                    ("c5", {}, "C5 bf16 dim 768, 32 x 256 tokens (BASELINE configs[4])"),
+                                    ("dep768", {}, "reference default deployment: dim 768, fp16 index, doclens N(200,80) in 8..384 "
+                                                   "(proj_conf/dense.yaml:6-8, encoder.py:175)")):
+                o, keep = extra_workload(colbert_amd, name, dev, xs, xw, label=label, **kw)
+                others.append(o)
+                keep = None
+                torch.cuda.empty_cache()
+            if "read_ceiling" in rf:
+                for o in others:
+                    o["frac_of_read_ceiling"] = round(o["achieved"] / rf["read_ceiling"]["GBps"], 4)
+            res["other_workloads"] = others
+        if full:
             res["training_form"] = training_form_probe(dev)
-        if world == 1 and not args.no_cpu_baseline and args.workload == "c2":
             res["cpu_baseline"] = cpu_baseline()
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(res) + "\n").encode())
@@ -381,12 +607,11 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     list in, python lists out, host-synchronous -- latency, not throughput.  `gpu_span_ms` is the time between two HIP
     events recorded on the launch stream right before and after the call (both kernels + the gap between them);
     `host_ms` = end-to-end minus that span (the events themselves add a few us to the span: the kernel's own duration is
-    in profiles/r02_single_query_*)."""
+    in profiles/r03_single_query_*)."""
     Q1 = Q[:1].float().permute(0, 2, 1)     # [1, h, Lq]: the permuted VIEW of a [1, Lq, h] tensor, as faiss_indexers.py:232-233 hands it over
     out = {"call": "rank_forward(Q[1,h,Lq], 1000 pids, depth=100) -> python lists"}
     lat, span = [], []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    import ctypes
     from colbert_amd import _lib
     Qt = Q1.permute(0, 2, 1).contiguous()   # (what rank_forward makes of it: the original layout, no copy)
     for it in range(160):
@@ -412,7 +637,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     out.update({"median_ms": round(med, 4), "min_ms": round(lat[0] * 1e3, 4), "gpu_span_ms": round(gspan, 4),
                 "host_ms": round(max(med - gspan, 0.0), 4), "queries_per_s_sequential": round(1e3 / med, 1),
                 "algorithmic_GBps_over_gpu_span": round((ntok * H * esize + LQ * H * 4) / (gspan * 1e-3) / 1e9, 1),
-                "kernel_profile": "profiles/r02_single_query_summary.json"})
+                "kernel_profile": "profiles/r03_single_query_summary.json"})
     # 16 queries per launch (a small server batch): the rerank kernel alone, 20 launches back to back between two events
     ks = []
     for rep in range(5):
@@ -432,9 +657,9 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
 def training_form_probe(dev):
     """The operator's second caller: BaseModel.score on the gathered training batch (colbert_model.py:87-90),
     every query against every doc, at the reference's step -- Q 272 x 32 x 768, D 544 x 384 x 768 bf16 (dense.yaml:6-8) --
-    through maxsim_score_dense_fwd (scores + arg-max for the backward).  Matrix-bound, unlike the rerank path: priced
-    against the dense bf16 MFMA peak.  Not the headline metric; one line so that the number is in the bench record."""
-    import torch.nn.functional as F
+    through maxsim_score_dense_fwd (scores + arg-max for the backward) and maxsim_score_dense_bwd (dQ and dD through the
+    saved arg-max).  Matrix-bound, unlike the rerank path: the forward is priced against the dense bf16 MFMA peak.  Not the
+    headline metric; one entry so that the numbers are in the bench record."""
     from colbert_amd import _lib
     from colbert_amd.scoring import _DT, _MDT
     nq, nd, lq, ld, h = 272, 544, 32, 384, 768
@@ -445,27 +670,42 @@ def training_form_probe(dev):
     dm = (torch.arange(ld, device=dev)[None, :] < torch.randint(ld // 4, ld + 1, (nd, 1), generator=g, device=dev)).float()
     out = torch.empty(nq, nd, device=dev)
     arg = torch.empty(nq, nd, lq, dtype=torch.int32, device=dev)
+    gout = torch.randn(nq, nd, generator=g, device=dev)
+    dQ = torch.empty(nq, lq, h, device=dev)
+    dD = torch.empty(nd, ld, h, device=dev)
+    wsb = int(_lib.lib.maxsim_score_dense_bwd_workspace(nq, nd, lq, ld))
+    ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
     st = torch.cuda.current_stream().cuda_stream
+    bf, mf = _DT[torch.bfloat16], _MDT[torch.float32]
 
-    def launch():
+    def fwd():
         rc = _lib.lib.maxsim_score_dense_fwd(Qt.data_ptr(), Dt.data_ptr(), qm.data_ptr(), dm.data_ptr(), nq, nd, lq, ld, h,
-                                             _DT[torch.bfloat16], _MDT[torch.float32], out.data_ptr(), arg.data_ptr(), st)
+                                             bf, mf, out.data_ptr(), arg.data_ptr(), st)
         assert rc == 0, rc
-    for _ in range(3):
-        launch()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
-    e0.record()
-    for _ in range(n):
-        launch()
-    e1.record()
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / n
+
+    def bwd():
+        rc = _lib.lib.maxsim_score_dense_bwd(Qt.data_ptr(), Dt.data_ptr(), qm.data_ptr(), dm.data_ptr(), arg.data_ptr(),
+                                             gout.data_ptr(), nq, nd, lq, ld, h, bf, mf, dQ.data_ptr(), dD.data_ptr(),
+                                             ws.data_ptr(), wsb, st)
+        assert rc == 0, rc
+
+    def t(f, n=20):
+        for _ in range(3):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / n
+    ms, bms = t(fwd), t(bwd)
     flop = 2.0 * nq * nd * lq * ld * h
-    return {"op": "maxsim_score_dense_fwd (scores + arg-max), Q 272x32x768 x D 544x384x768, bf16, prefix d_mask",
-            "kernel": "k_maxsim_allpairs" if _lib.lib.maxsim_score_dense_kernel(nq, nd, lq, ld, h, _DT[torch.bfloat16], _MDT[torch.float32]) == 1 else "k_maxsim_stream_bigh",
-            "forward_ms": round(ms, 4), "tflops": round(flop / ms / 1e9, 1), "peak_tflops_dense_bf16": 2500.0,
-            "frac": round(flop / ms / 1e9 / 2500.0, 4), "how": f"{n} launches back to back between two HIP events",
+    return {"op": "maxsim_score_dense_fwd (scores + arg-max) / maxsim_score_dense_bwd (dQ, dD), Q 272x32x768 x D 544x384x768, bf16, prefix d_mask",
+            "kernel": "k_maxsim_allpairs" if _lib.lib.maxsim_score_dense_kernel(nq, nd, lq, ld, h, bf, mf) == 1 else "k_maxsim_stream_bigh",
+            "forward_ms": round(ms, 4), "backward_ms": round(bms, 4), "forward_backward_ms": round(ms + bms, 4),
+            "tflops": round(flop / ms / 1e9, 1), "peak_tflops_dense_bf16": 2500.0,
+            "frac": round(flop / ms / 1e9 / 2500.0, 4), "how": "20 launches back to back between two HIP events, forward and backward separately",
             "profile": "profiles/r02_allpairs_kernel_stats.csv, profiles/r02_allpairs_pmc.json"}
 
 

@@ -12,6 +12,7 @@
 #include "maxsim_common.h"
 #include "maxsim_generic.h"
 #include "maxsim_launch.h"
+#include "maxsim_probe.h"
 #include "maxsim_shard.h"
 #include "maxsim_topk.h"
 #include "maxsim_worklist.h"
@@ -415,6 +416,32 @@ int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype,
     }
   }
   return hipStreamSynchronize(st) == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
+}
+
+int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* bytes_read, void* stream) {
+  if (!buf || bytes < 0 || variant < 0 || variant > 2 || ((uintptr_t)buf & 15) != 0) return MAXSIM_EINVAL;
+  // a wave reads 32 tiles of 16 KiB (variant 1: 64 tiles of 8 KiB) = 512 KiB, a workgroup of 4 waves 2 MiB
+  const int64_t per_wave = 512 * 1024;
+  const int64_t wgs = bytes / (4 * per_wave);
+  if (bytes_read) *bytes_read = wgs * 4 * per_wave;
+  if (wgs == 0) return MAXSIM_OK;
+  if (wgs > 0x7fffffffLL) return MAXSIM_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  int rc = MAXSIM_OK;
+  switch (variant) {
+    case 0:  // the fp32 rerank kernel's shape: one 16 KiB tile per wave, 8 waves per CU
+      hipLaunchKernelGGL((k_read_probe<16384, 1>), dim3((unsigned)wgs), dim3(256), 4 * 16384, st, (const char*)buf, per_wave);
+      break;
+    case 1:  // the 16-bit kernels' shape: two 8 KiB tiles per wave
+      hipLaunchKernelGGL((k_read_probe<8192, 2>), dim3((unsigned)wgs), dim3(256), 4 * 2 * 8192, st, (const char*)buf, per_wave);
+      break;
+    default:  // two 16 KiB tiles per wave, one workgroup per CU
+      rc = allow_lds(k_read_probe<16384, 2>, 4 * 2 * 16384);
+      if (rc) return rc;
+      hipLaunchKernelGGL((k_read_probe<16384, 2>), dim3((unsigned)wgs), dim3(256), 4 * 2 * 16384, st, (const char*)buf, per_wave);
+      break;
+  }
+  return check_launch();
 }
 
 int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,

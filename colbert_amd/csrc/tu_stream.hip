@@ -142,6 +142,7 @@ int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_
   int64_t wgs = (max_items + 3) / 4;
   if (wgs < 1) wgs = 1;
   if (wgs > cap) wgs = cap;
+  wgs = (wgs + 7) & ~(int64_t)7;  // the kernel's slot -> item map assumes a workgroup's slots share s % 8
   if (p.Lq <= 16 && index_dtype == MAXSIM_F32) return launch_list_v<MAXSIM_F32, 16>(p, (int)wgs, st);
   switch (index_dtype) {
     case MAXSIM_F32: return launch_list_v<MAXSIM_F32, QT_2X16>(p, (int)wgs, st);

@@ -79,6 +79,29 @@ def global_strides(local_doclens, group=None, device=None):
     return strides_from_histogram(hist.cpu())
 
 
+def assert_strides_agree(strides, group=None, device=None):
+    """Fails loudly when the ranks of a doc-sharded index do not bucket by the same strides (a shard built with
+    ``sync_strides=False`` from its own percentiles, a rank that loaded another index): the 0-floor -- and therefore
+    the scores -- would silently differ from the unsharded reference (colbert_ranker.py:90, :108-109).  One small
+    all_reduce(MAX) of (strides, -strides)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    st = sorted(int(x) for x in strides)
+    if len(st) > 4:
+        raise ValueError(f"at most 4 distinct strides (colbert_ranker.py:36-40), got {st}")
+    v = torch.tensor([len(st)] + st + [0] * (4 - len(st)), dtype=torch.int64)
+    both = torch.cat([v, -v])
+    if device is None and dist.get_backend(group) == "nccl":
+        device = torch.device("cuda", torch.cuda.current_device())
+    both = both.to(device) if device is not None else both
+    dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
+    both = both.cpu()
+    if not torch.equal(both[:5], -both[5:]):
+        raise RuntimeError(f"doc shards disagree on the length-bucket strides: this rank has {st}, the ranks' maxima are "
+                           f"{both[1:5].tolist()} and minima {(-both[6:]).tolist()} -- every shard must use the strides "
+                           f"of the WHOLE index (sharded.global_strides)")
+
+
 def all_gather_topk(top_s, top_p, world, group=None):
     """The path's ONE exchange step: every rank's [nq, k] scores and global pids -> [world, nq, k] on every rank.
     Scores travel as their bit patterns next to the pids in one int64 payload, so it is a single collective."""
@@ -120,9 +143,13 @@ class ShardedRanker:
         self.exchange_events = None   # diagnostic: a list here collects (start, stop) HIP events of every exchange + merge
         # bucket by the strides of the whole index (see the module docstring); every rank must construct its
         # ShardedRanker at the same point (two small all_reduces)
-        if sync_strides and hasattr(local_ranker, "set_strides") and self._world() > 1:
+        if hasattr(local_ranker, "set_strides") and self._world() > 1:
             dev = local_ranker.device if local_ranker.device.type == "cuda" else None
-            local_ranker.set_strides(global_strides(local_ranker.doclens, group, dev))
+            if sync_strides:
+                local_ranker.set_strides(global_strides(local_ranker.doclens, group, dev))
+            # sync_strides=False (the caller set the strides itself) is still checked: ranks that bucket differently
+            # would return scores that differ from the unsharded reference without any error
+            assert_strides_agree(local_ranker.strides, group, dev)
 
     def local_topk(self, Q, cand_global, depth, q_len=None, q_mask=None):
         """Scores this shard's share of every query's GLOBAL candidate list and returns its local top-k with global pids:

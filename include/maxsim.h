@@ -274,6 +274,16 @@ int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtyp
 int maxsim_topk_counted(const float* scores, const int64_t* pids, const int32_t* counts, int nq, int ncand, int k,
                         float* out_scores, int64_t* out_pids, void* stream);
 
+/*
+ * Measurement aid ("measure achievable with a copy/read microbench on the box"): streams the first
+ * `bytes` (rounded down to a multiple of 2 MiB, returned in *bytes_read when given) of a device buffer through the rerank
+ * kernels' own fetch path -- non-temporal LDS-DMA into per-wave LDS rings -- and consumes nothing.  Timing this launch
+ * with HIP events gives the read rate the memory system delivers to that access pattern on this box, the ceiling
+ * bench.py reports as roofline.read_ceiling next to the 8 TB/s spec peak.  variant: 0 = one 16 KiB tile per wave (the fp32
+ * kernel's ring), 1 = two 8 KiB tiles (the 16-bit kernels' ring), 2 = two 16 KiB tiles.  buf must be 16-byte aligned.
+ */
+int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* bytes_read, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,9 +96,24 @@ def _worker(rank, world, port, ret):
         own_strides = list(local.strides)
         gs = global_strides(doclens[lo:hi])
         checks = {'global_strides': gs == whole.strides, 'not_vacuous': own_strides != whole.strides}
-        local.strides = gs
+        # the SHIPPED constructor under a real process group: ShardedRanker.__init__ derives the strides of the whole
+        # index (two all_reduces, sharded.py) and re-buckets the shard's ColbertRanker through set_strides; the oracle
+        # scorer then buckets by whatever strides that left behind
+        import colbert_amd
+        cr = colbert_amd.ColbertRanker(parts=[emb[offs[lo]:offs[hi]]], parts_doclens=[doclens[lo:hi]], dim=emb.size(1), device="cpu")
+        checks['ctor_own_strides_first'] = cr.strides == own_strides
+        sh = ShardedRanker(cr, lo, hi, score_fn=make_scorer(local), topk_fn=cpu_topk)
+        checks['ctor_global_strides'] = cr.strides == whole.strides
+        checks['ctor_pad_len'] = torch.equal(cr.d_pad_len.long(), whole.bucket_strides(list(range(lo, hi))))
+        local.strides = list(cr.strides)
         local.views = local._create_views(local.tensor)
-        sh = ShardedRanker(object(), lo, hi, score_fn=make_scorer(local), topk_fn=cpu_topk)
+        # a rank that keeps its own percentiles (sync_strides=False) is an error, not a silently different score
+        cr_own = colbert_amd.ColbertRanker(parts=[emb[offs[lo]:offs[hi]]], parts_doclens=[doclens[lo:hi]], dim=emb.size(1), device="cpu")
+        try:
+            ShardedRanker(cr_own, lo, hi, score_fn=make_scorer(local), topk_fn=cpu_topk, sync_strides=False)
+            checks['disagreeing_strides_raise'] = False
+        except RuntimeError as e:
+            checks['disagreeing_strides_raise'] = "disagree" in str(e)
         top_p, top_s = sh.rerank_batch(Q, cand, depth=K)
         checks['sharded_eq_whole'] = same_ranking(top_p, top_s, exp, cand, K)
         top_p, top_s = sh.rerank_batch(Q, cand, depth=5)
