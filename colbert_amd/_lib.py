@@ -18,7 +18,8 @@ SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_re
            "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
            "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_rank_forward_workspace_bytes", "maxsim_doc_table_bytes",
            "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel", "maxsim_worklist_bytes",
-           "maxsim_rerank_counted", "maxsim_topk_counted", "maxsim_hbm_read_probe")
+           "maxsim_rerank_counted", "maxsim_topk_counted", "maxsim_hbm_read_probe",
+           "maxsim_host_alloc_coherent", "maxsim_host_free")
 
 
 class IndexView(ctypes.Structure):
@@ -81,6 +82,10 @@ def _load():
     lib.maxsim_rerank_counted.argtypes = [ivp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, i64, vp]
     lib.maxsim_topk_counted.restype = i32
     lib.maxsim_topk_counted.argtypes = [vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    lib.maxsim_host_alloc_coherent.restype = vp
+    lib.maxsim_host_alloc_coherent.argtypes = [i64]
+    lib.maxsim_host_free.restype = None
+    lib.maxsim_host_free.argtypes = [vp]
     lib.maxsim_hbm_read_probe.restype = i32
     lib.maxsim_hbm_read_probe.argtypes = [vp, i64, i32, vp, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32

@@ -1,24 +1,14 @@
 """Host-COHERENT pinned memory for the buffers the GPU and the host exchange while a kernel is still running
 (``rank_forward``: the kernel reads the pid list from, and writes the top-k and its completion word to, host memory
 that the host polls).  torch's ``pin_memory()`` gives no coherence guarantee before a synchronisation point, so these
-few KB are allocated with ``hipHostMalloc(hipHostMallocCoherent)`` directly."""
+few KB are allocated with ``hipHostMalloc(hipHostMallocCoherent)`` -- through ``maxsim_host_alloc_coherent``, i.e. by the
+HIP runtime libmaxsim itself is linked against (resolving ``libamdhip64.so`` by name here could load a second runtime
+whose allocations the first one does not know)."""
 import ctypes
 
 import numpy as np
 
-_HIP_HOST_MALLOC_COHERENT = 0x40000000
-_hip = None
-
-
-def _lib():
-    global _hip
-    if _hip is None:
-        _hip = ctypes.CDLL("libamdhip64.so")      # the runtime torch already loaded
-        _hip.hipHostMalloc.restype = ctypes.c_int
-        _hip.hipHostMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t, ctypes.c_uint]
-        _hip.hipHostFree.restype = ctypes.c_int
-        _hip.hipHostFree.argtypes = [ctypes.c_void_p]
-    return _hip
+from . import _lib
 
 
 class PinnedBuffer:
@@ -26,11 +16,10 @@ class PinnedBuffer:
     valid on the host and on the device (unified addressing)."""
 
     def __init__(self, nbytes):
-        p = ctypes.c_void_p()
-        rc = _lib().hipHostMalloc(ctypes.byref(p), nbytes, _HIP_HOST_MALLOC_COHERENT)
-        if rc != 0 or not p.value:
-            raise MemoryError(f"hipHostMalloc({nbytes}, coherent) failed with {rc}")
-        self.ptr, self.nbytes = p.value, nbytes
+        p = _lib.lib.maxsim_host_alloc_coherent(int(nbytes))
+        if not p:
+            raise MemoryError(f"maxsim_host_alloc_coherent({nbytes}) failed")
+        self.ptr, self.nbytes = int(p), nbytes
         self._raw = (ctypes.c_char * nbytes).from_address(self.ptr)
 
     def view(self, dtype, offset, count):
@@ -39,7 +28,7 @@ class PinnedBuffer:
     def __del__(self):
         try:
             if getattr(self, "ptr", None):
-                _lib().hipHostFree(self.ptr)
+                _lib.lib.maxsim_host_free(self.ptr)
                 self.ptr = None
         except Exception:  # interpreter shutdown
             pass

@@ -13,16 +13,19 @@ typedef int (*rank_forward_fn)(const void* iv, const void* Q, int q_dtype, int L
                                void* workspace, int64_t* out_pids, float* out_scores, uint32_t* done_flag, int sync,
                                void* stream);
 
-/* rank_forward(fn, iv, Q, q_dtype, Lq, pids: list[int], depth, pin_in, scratch, out_pids, out_scores, flag, stream)
- *   -> (pids: list[int], scores: list[float])  or  int (a negative MAXSIM_E* code: the caller raises)
+/* rank_forward(fn, iv, Q, q_dtype, Lq, pids: list[int], depth, pin_in, scratch, out_pids, out_scores, flag, stream, n_docs)
+ *   -> (pids: list[int], scores: list[float])  or  int (a negative MAXSIM_E* code: the caller raises)  or  None (the list
+ *      holds negative pids in [-n_docs, -1]: torch indexing wraps them, colbert_ranker.py:88 -- the caller's general path does)
+ * A pid >= n_docs or < -n_docs raises IndexError, as `self.doclens[pids]` does at colbert_ranker.py:88.
  * All pointers are integers (addresses).  pin_in must hold len(pids) int64. */
 static PyObject* fr_rank_forward(PyObject* self, PyObject* args) {
   unsigned long long fn, iv, q, pin_in, scratch, out_p, out_s, flag, stream;
+  long long n_docs;
   int q_dtype, Lq, depth;
   PyObject* pids;
   (void)self;
-  if (!PyArg_ParseTuple(args, "KKKiiOiKKKKKK", &fn, &iv, &q, &q_dtype, &Lq, &pids, &depth, &pin_in, &scratch, &out_p, &out_s,
-                        &flag, &stream))
+  if (!PyArg_ParseTuple(args, "KKKiiOiKKKKKKL", &fn, &iv, &q, &q_dtype, &Lq, &pids, &depth, &pin_in, &scratch, &out_p, &out_s,
+                        &flag, &stream, &n_docs))
     return NULL;
   if (!PyList_CheckExact(pids)) {
     PyErr_SetString(PyExc_TypeError, "pids must be a list");
@@ -34,6 +37,7 @@ static PyObject* fr_rank_forward(PyObject* self, PyObject* args) {
     return NULL;
   }
   int64_t* const dst = (int64_t*)(uintptr_t)pin_in;
+  int64_t lo = INT64_MAX, hi = INT64_MIN;
   for (Py_ssize_t i = 0; i < n; ++i) {
     PyObject* const o = PyList_GET_ITEM(pids, i);
     if (!PyLong_Check(o)) {
@@ -45,14 +49,25 @@ static PyObject* fr_rank_forward(PyObject* self, PyObject* args) {
     const Py_ssize_t sz = Py_SIZE(o);
     if ((size_t)sz <= 2) {
       const digit* const dg = ((PyLongObject*)o)->ob_digit;
-      dst[i] = sz == 0 ? 0 : sz == 1 ? (int64_t)dg[0] : (int64_t)dg[0] | ((int64_t)dg[1] << 30);
+      const int64_t u = sz == 0 ? 0 : sz == 1 ? (int64_t)dg[0] : (int64_t)dg[0] | ((int64_t)dg[1] << 30);
+      dst[i] = u;
+      hi = u > hi ? u : hi;
+      lo = u < lo ? u : lo;
       continue;
     }
 #endif
     const long long v = PyLong_AsLongLong(o);
     if (v == -1 && PyErr_Occurred()) return NULL;
     dst[i] = (int64_t)v;
+    hi = v > hi ? v : hi;
+    lo = v < lo ? v : lo;
   }
+  if (hi >= (int64_t)n_docs || lo < -(int64_t)n_docs) {  /* self.doclens[pids], colbert_ranker.py:88 */
+    PyErr_Format(PyExc_IndexError, "index %lld is out of bounds for dimension 0 with size %lld",
+                 (long long)(hi >= (int64_t)n_docs ? hi : lo), n_docs);
+    return NULL;
+  }
+  if (lo < 0) Py_RETURN_NONE;
   const int k = depth < (int)n ? depth : (int)n;
   int rc;
   Py_BEGIN_ALLOW_THREADS

@@ -21,6 +21,17 @@ using namespace maxsim;
 
 namespace {
 
+// one spin of a host-side polling loop (maxsim_rank_forward waits for the top-k kernel's completion word)
+inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__)
+  asm volatile("yield" ::: "memory");
+#else
+  std::atomic_signal_fence(std::memory_order_seq_cst);
+#endif
+}
+
 // Queries longer than 32 tokens: score(Q) = sum over 32-token slices of score(slice) (the sum over query tokens
 // is additive), one launch per slice, the later ones accumulating into `scores`.
 template <typename F>
@@ -412,10 +423,20 @@ int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype,
         std::atomic_thread_fence(std::memory_order_acquire);
         return MAXSIM_OK;
       }
-      __builtin_ia32_pause();
+      cpu_relax();
     }
   }
   return hipStreamSynchronize(st) == hipSuccess ? MAXSIM_OK : MAXSIM_ELAUNCH;
+}
+
+void* maxsim_host_alloc_coherent(int64_t bytes) {
+  void* p = nullptr;
+  if (bytes <= 0 || hipHostMalloc(&p, (size_t)bytes, hipHostMallocCoherent) != hipSuccess) return nullptr;
+  return p;
+}
+
+void maxsim_host_free(void* p) {
+  if (p) (void)hipHostFree(p);
 }
 
 int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* bytes_read, void* stream) {

@@ -306,13 +306,7 @@ class ColbertRanker:
             Qt = Qt.contiguous()
         assert Qt.size(2) == self.dim, (Qt.size(2), self.dim)
         if n_pids > BSIZE or output_D_embedding:
-            pids_t = torch.tensor(pids) if type(pids) is list else pids
-            cand = pids_t.to(dev, torch.int64).view(1, -1)
-            scores = self.score_candidates(Qt, cand)
-            top_p, top_s = self.topk(scores, cand, k)                         # :128-130
-            if output_D_embedding:                                            # :131-136
-                return self._output_D(top_p[0], k)
-            return top_p[0].tolist(), top_s[0].tolist()
+            return self._rank_forward_general(Qt, pids, k, output_D_embedding)
         # the online call: ONE library call (rerank + top-k enqueued back to back, then a poll on the completion word the
         # top-k kernel stores).  The pid list goes in through pinned host memory the kernels read directly and the top-k
         # comes out through host-coherent pinned memory they write directly: no memcpy calls, no allocations (per-thread
@@ -327,26 +321,33 @@ class ColbertRanker:
             try:
                 r = _fastrank.rank_forward(_RANK_FORWARD_FN, ctypes.addressof(self._iv), Qt.data_ptr(), _DT[qdt], Qt.size(1),
                                            pids, k, ws.in_ptr, ws.scratch_ptr, ws.out_p_ptr, ws.out_s_ptr, ws.flag_ptr,
-                                           torch._C._cuda_getCurrentRawStream(idx))
+                                           torch._C._cuda_getCurrentRawStream(idx), self.n_docs)
             except (TypeError, OverflowError):
                 r = None
             if r is not None:
                 if type(r) is int:
                     _lib.check(r, "maxsim_rank_forward")
                 return r
+        # `self.doclens[pids]` (:88): a pid >= n_docs or < -n_docs raises IndexError, one in [-n_docs, -1] wraps
         if type(pids) is list:
             try:        # 1000 python ints: 8 us through array('q') against 50-75 us for torch.tensor(list)
                 a = array.array("q", pids)
                 ctypes.memmove(ws.in_ptr, a.buffer_info()[0], 8 * n_pids)
             except (TypeError, OverflowError):
                 ws.pin_in[:n_pids] = np.asarray(pids, dtype=np.int64)
+            lo, hi = int(ws.pin_in[:n_pids].min()), int(ws.pin_in[:n_pids].max())
             pid_ptr = ws.in_ptr
         elif pids.is_cuda:
             pid_keep = pids.to(dev, torch.int64).contiguous()
+            lo, hi = (int(x) for x in torch.aminmax(pid_keep))
             pid_ptr = pid_keep.data_ptr()
         else:
             ws.pin_in[:n_pids] = pids.to(torch.int64).numpy()
+            lo, hi = int(ws.pin_in[:n_pids].min()), int(ws.pin_in[:n_pids].max())
             pid_ptr = ws.in_ptr
+        self._check_pid_range(lo, hi)
+        if lo < 0:
+            return self._rank_forward_general(Qt, pids, k, False)
         switch = torch.cuda.current_device() != idx
         if switch:
             prev = torch.cuda.current_device()
@@ -361,18 +362,42 @@ class ColbertRanker:
         _lib.check(rc, "maxsim_rank_forward")
         return ws.pin_out_p[:k].tolist(), ws.pin_out_s[:k].tolist()
 
-    def _output_D(self, top_pids, k):
-        """colbert_ranker.py:131-136: padded D [k, S, h] and mask of the top docs.  The reference's
-        ``torch.cat(output_D)`` only works when all candidates fall in ONE length bucket; same restriction."""
-        pad = self.d_pad_len[top_pids].to(torch.int64)
+    def _check_pid_range(self, lo, hi):
+        """``self.doclens[pids]`` (colbert_ranker.py:88) raises IndexError for an index outside [-n_docs, n_docs)."""
+        if hi >= self.n_docs or lo < -self.n_docs:
+            raise IndexError(f"index {hi if hi >= self.n_docs else lo} is out of bounds for dimension 0 with size {self.n_docs}")
+
+    def _rank_forward_general(self, Qt, pids, k, output_D_embedding):
+        """rank_forward through the batched entry points: lists longer than BSIZE, ``output_D_embedding``, and pid lists
+        with negative entries.  Negative pids index from the end, as torch indexing does at colbert_ranker.py:88; the
+        returned pids are the caller's own values (:129 returns ``pids[order]``).  (The reference pairs ``doclens[pid]``
+        with ``doclens_pfxsum[pid]`` of a table that is one entry longer, so for a negative pid it would read the NEXT doc's
+        tokens with this doc's length -- a latent misalignment that is not reproduced: both wrap consistently here.)"""
+        dev = self.device
+        pids_t = (torch.tensor(pids) if type(pids) is list else pids).to(dev, torch.int64).view(1, -1)
+        lo, hi = (int(x) for x in torch.aminmax(pids_t))
+        self._check_pid_range(lo, hi)
+        cand = torch.where(pids_t < 0, pids_t + self.n_docs, pids_t) if lo < 0 else pids_t
+        scores = self.score_candidates(Qt, cand)
+        top_p, top_s = self.topk(scores, pids_t, k)                           # :128-130
+        if output_D_embedding:                                                # :131-136
+            top_c, _ = self.topk(scores, cand, k)
+            return self._output_D(top_p[0], top_c[0], cand[0])
+        return top_p[0].tolist(), top_s[0].tolist()
+
+    def _output_D(self, top_pids, top_rows, all_cand):
+        """colbert_ranker.py:131-136: D [k, S, h] fp32 and mask [k, S] of the top docs, as the reference's strided view
+        hands them over (:49, :105): slot t of a doc is token row offset + t of the concatenated index WHATEVER doc it
+        belongs to -- slots past the doc's end hold the next docs' tokens (zeros past the end of the index: the
+        reference's +512-row tail, :62) and are flagged only by the mask.  The reference's ``torch.cat(output_D)`` (:132)
+        works only when ALL candidates fall in ONE length bucket; same restriction, same error."""
+        pad = self.d_pad_len[all_cand].to(torch.int64)
         S = int(pad.max().item())
         if not bool((pad == S).all()):
             raise RuntimeError("Sizes of tensors must match except in dimension 0 (candidates span several length buckets)")
-        rows = self.d_offsets[top_pids].unsqueeze(1) + torch.arange(S, device=self.device).unsqueeze(0)
-        mask = torch.arange(S, device=self.device).unsqueeze(0) + 1 <= self.d_doclens[top_pids].unsqueeze(1)
-        rows = rows.clamp(max=max(self.num_embeddings - 1, 0))
-        D = self.tensor[rows].to(self.maxsim_dtype)
-        # slots past the doc end alias the next doc's tokens in the reference view (:49); they are only ever used
-        # under the mask, so they are returned zeroed here
-        D = D * mask.unsqueeze(-1)
+        rows = self.d_offsets[top_rows].unsqueeze(1) + torch.arange(S, device=self.device).unsqueeze(0)
+        mask = torch.arange(S, device=self.device).unsqueeze(0) + 1 <= self.d_doclens[top_rows].unsqueeze(1)   # :108-109
+        inside = rows < self.num_embeddings
+        D = self.tensor[rows.clamp(max=max(self.num_embeddings - 1, 0))].to(self.maxsim_dtype)
+        D = D * inside.unsqueeze(-1)                                          # the zero tail behind the last doc
         return top_pids.tolist(), D, mask

@@ -105,8 +105,13 @@ int maxsim_score_dense(const void* Q, const void* D, const void* q_mask, const v
  */
 /* Which kernel serves an all-pairs problem of this shape with 16-byte aligned operands: 1 = the GEMM-blocked kernel
  * (16-bit Q and D of one type, h % 64 == 0, h >= 128, Lq <= 32, Ld <= 384, float32 masks or none, Q and D below 3.75 GB
- * each, at least 128 (doc, 8-query) tiles), 0 = the streaming / generic kernels (everything else).  Results are the
- * same either way; tests and benchmarks use this to say what they measured.  Negative: MAXSIM_EINVAL. */
+ * each, at least 128 (doc, 8-query) tiles), 0 = the streaming / generic kernels (everything else).  With 0/1 masks (what
+ * the reference passes: tokenizers.py:57 prefix masks, q_mask of ones) the two give the same scores and the same arg-max.
+ * With general float masks they agree to 16-bit rounding only: BaseModel.score multiplies Q and D by their masks in the
+ * operand dtype before the matmul, as the streaming kernel does, while the GEMM-blocked kernel weighs the finished fp32
+ * similarities (d_mask) and the maximum (non-negative q_mask) -- more accurate, not bit-identical, and a tie created by
+ * the weighting can move the first-max arg-max.  Tests and benchmarks use this function to say what they measured.
+ * Negative: MAXSIM_EINVAL. */
 int maxsim_score_dense_kernel(int nq, int nd, int Lq, int Ld, int h, int dtype, int mask_dtype);
 
 int maxsim_score_dense_fwd(const void* Q, const void* D, const void* q_mask, const void* d_mask, int nq, int nd,
@@ -273,6 +278,15 @@ int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtyp
                           int Lq, float* scores, void* worklist, int64_t worklist_bytes, void* stream);
 int maxsim_topk_counted(const float* scores, const int64_t* pids, const int32_t* counts, int nq, int ncand, int k,
                         float* out_scores, int64_t* out_pids, void* stream);
+
+/*
+ * Host-COHERENT pinned memory for the buffers of maxsim_rank_forward that the host reads while the kernel may still be
+ * running (out_pids, out_scores, done_flag): hipHostMalloc(hipHostMallocCoherent) from the HIP runtime THIS library is
+ * linked against (a caller that resolved the runtime by name could load a second copy whose allocations the first does
+ * not know).  The pointer is valid on the host and on every device.  NULL on failure.  Free with maxsim_host_free.
+ */
+void* maxsim_host_alloc_coherent(int64_t bytes);
+void maxsim_host_free(void* p);
 
 /*
  * Measurement aid ("measure achievable with a copy/read microbench on the box"): streams the first

@@ -139,6 +139,34 @@ def main():
     qm, dm = torch.ones(1, 32, dtype=torch.long), torch.ones(3, 200, dtype=torch.long)
     save("c5_bf16_768", Q=Q, D=D, q_mask=qm, d_mask=dm, expected=check(Q.float(), D.float(), qm, dm))
 
+    # (8) the reference's DEFAULT deployment shape (proj_conf/dense.yaml:6-8: dim 768; encoder.py:175: fp16 index) as a
+    #     ragged rerank: 16 docs of 1..48 tokens incl. docs exactly at / next to every percentile stride, one query and
+    #     one "negative" query whose score the 0-floor decides -- same construction as (5), dim 768
+    g = torch.Generator().manual_seed(8)
+    ndocs, dim, Lq = 16, 768, 32
+    doclens = torch.randint(1, 41, (ndocs,), generator=g)
+    doclens[:3] = torch.tensor([48, 47, 1])
+    srt = doclens.sort().values
+    p25, p50, p75 = (int(srt[int(p * ndocs / 100.0) - 1]) for p in (25, 50, 75))
+    doclens[3:9] = torch.tensor([p25, p25 + 1, p50, p50 - 1, p75, p75 + 1]).clamp(min=1)
+    doclens = doclens.tolist()
+    parts_doclens = [doclens[:7], doclens[7:]]
+    parts = [norm_randn(g, sum(dl), dim).half() for dl in parts_doclens]
+    ranker = RefRanker(parts, parts_doclens, dim=dim, score_fn=REF)
+    q = norm_randn(g, Lq, dim)
+    Qr = q.unsqueeze(0).permute(0, 2, 1).contiguous()
+    pids = torch.randperm(ndocs, generator=g).tolist()
+    all_scores = ranker.all_scores(Qr, pids)
+    top_p, top_s = ranker.rank_forward(Qr, pids, depth=10)
+    qneg = F.normalize(-parts[1][:Lq].float() + 0.05 * norm_randn(g, Lq, dim), dim=-1)
+    Qn = qneg.unsqueeze(0).permute(0, 2, 1).contiguous()
+    all_scores_neg = ranker.all_scores(Qn, pids)
+    save("ragged_rerank_768", part0=parts[0], part1=parts[1], doclens0=np.array(parts_doclens[0]),
+         doclens1=np.array(parts_doclens[1]), strides=np.array(ranker.strides),
+         pad_len=ranker.bucket_strides(list(range(ndocs))), Q=Qr, Q_neg=Qn, pids=np.array(pids),
+         expected_scores=all_scores, expected_scores_neg=all_scores_neg,
+         top10_pids=np.array(top_p), top10_scores=np.array(top_s, dtype=np.float64))
+
     # dtype propagation facts: fp32*int64 -> fp32 ; fp16*int64 -> fp16
     a = REF(torch.ones(1, 2, 4), torch.ones(1, 2, 4), torch.ones(1, 2, dtype=torch.long), torch.ones(1, 2, dtype=torch.long))
     assert a.dtype == torch.float32

@@ -105,19 +105,19 @@ def test_fastrank_glue_loads_and_validates():
     assert ranker._RANK_FORWARD_FN
     import pytest
     with pytest.raises(TypeError):
-        fr.rank_forward(1, 2, 3, 0, 32, (1, 2), 10, 4, 5, 6, 7, 8, 9)            # not a list
+        fr.rank_forward(1, 2, 3, 0, 32, (1, 2), 10, 4, 5, 6, 7, 8, 9, 100)       # not a list
     with pytest.raises(ValueError):
-        fr.rank_forward(1, 2, 3, 0, 32, [], 10, 4, 5, 6, 7, 8, 9)                # empty
+        fr.rank_forward(1, 2, 3, 0, 32, [], 10, 4, 5, 6, 7, 8, 9, 100)           # empty
     with pytest.raises(ValueError):
-        fr.rank_forward(1, 2, 3, 0, 32, [1], 0, 4, 5, 6, 7, 8, 9)               # depth 0
+        fr.rank_forward(1, 2, 3, 0, 32, [1], 0, 4, 5, 6, 7, 8, 9, 100)          # depth 0
     with pytest.raises(ValueError):
-        fr.rank_forward(1, 2, 3, 0, 32, [1], 1, 0, 5, 6, 7, 8, 9)               # null input buffer
+        fr.rank_forward(1, 2, 3, 0, 32, [1], 1, 0, 5, 6, 7, 8, 9, 100)          # null input buffer
     import ctypes
     buf = (ctypes.c_int64 * 4)()
     with pytest.raises(TypeError):
-        fr.rank_forward(1, 2, 3, 0, 32, [1, 2.5], 1, ctypes.addressof(buf), 5, 6, 7, 8, 9)   # a float in the list
+        fr.rank_forward(1, 2, 3, 0, 32, [1, 2.5], 1, ctypes.addressof(buf), 5, 6, 7, 8, 9, 100)   # a float in the list
     with pytest.raises(OverflowError):
-        fr.rank_forward(1, 2, 3, 0, 32, [1, 2 ** 70], 1, ctypes.addressof(buf), 5, 6, 7, 8, 9)
+        fr.rank_forward(1, 2, 3, 0, 32, [1, 2 ** 70], 1, ctypes.addressof(buf), 5, 6, 7, 8, 9, 100)
     # the list lands in the input buffer exactly (one- and two-digit ints, negative and > 2^60 through the general
     # conversion) and a library error code comes back as an int: a stand-in for maxsim_rank_forward that returns -3
     big = (ctypes.c_int64 * 9)()
@@ -129,7 +129,17 @@ def test_fastrank_glue_loads_and_validates():
         seen.update(n=n, depth=depth, lq=lq, sync=rest[4])
         return -3
     cb = proto(stand_in)
-    vals = [0, 1, 2 ** 30 - 1, 2 ** 30, 2 ** 45 + 7, 2 ** 60 - 1, 2 ** 60, -5, 2 ** 63 - 1]
-    rc = fr.rank_forward(ctypes.cast(cb, ctypes.c_void_p).value, 2, 3, 0, 32, vals, 4, ctypes.addressof(big), 0, 6, 7, 8, 9)
+    vals = [0, 1, 2 ** 30 - 1, 2 ** 30, 2 ** 45 + 7, 2 ** 60 - 1, 2 ** 60, 5, 2 ** 63 - 2]
+    fn = ctypes.cast(cb, ctypes.c_void_p).value
+    rc = fr.rank_forward(fn, 2, 3, 0, 32, vals, 4, ctypes.addressof(big), 0, 6, 7, 8, 9, 2 ** 63 - 1)
     assert rc == -3 and list(big) == vals
     assert seen == {"n": 9, "depth": 4, "lq": 32, "sync": 1}
+    # `self.doclens[pids]` (colbert_ranker.py:88): a pid outside [-n_docs, n_docs) is an IndexError BEFORE anything is
+    # launched; a negative pid inside it is handed back (None) to the caller's general path, which wraps it as torch does
+    seen.clear()
+    with pytest.raises(IndexError, match="index 100 is out of bounds for dimension 0 with size 100"):
+        fr.rank_forward(fn, 2, 3, 0, 32, [3, 100, 7], 4, ctypes.addressof(big), 0, 6, 7, 8, 9, 100)
+    with pytest.raises(IndexError, match="index -101 is out of bounds"):
+        fr.rank_forward(fn, 2, 3, 0, 32, [3, -101, 7], 4, ctypes.addressof(big), 0, 6, 7, 8, 9, 100)
+    assert fr.rank_forward(fn, 2, 3, 0, 32, [3, -100, 99], 4, ctypes.addressof(big), 0, 6, 7, 8, 9, 100) is None
+    assert seen == {}                                                   # the library was not called in any of the three

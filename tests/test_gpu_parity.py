@@ -212,10 +212,25 @@ def test_ranker_from_index_files_and_output_D(ca, golden, tmp_path):
     ep, eD, em = ref.rank_forward(g["Q"], same, depth=4, output_D_embedding=True)
     gp, gD, gm = r.rank_forward(g["Q"], same, depth=4, output_D_embedding=True)
     assert gp == ep and tuple(gD.shape) == tuple(eD.shape) and torch.equal(gm.cpu(), em)
-    # slots under the mask are the doc's tokens; slots past the doc end are never used unmasked
-    torch.testing.assert_close(gD.cpu() * em.unsqueeze(-1), eD * em.unsqueeze(-1), rtol=0, atol=0)
+    # EVERY slot equals the reference's strided view (colbert_ranker.py:49,105): under the mask the doc's own tokens, past
+    # the doc's end the next docs' tokens (or the zero tail behind the last doc) -- no multiplication by the mask here
+    assert bool((~em).any()) and float(eD[~em].abs().max()) > 0            # the aliased slots exist and are not zero
+    torch.testing.assert_close(gD.cpu(), eD, rtol=0, atol=0)
+    # ... including the docs at the very end of the index, whose slots run into the +512 zero rows (:62)
+    last = [i for i in range(64) if int(pad[i]) == int(pad[63])][-5:]
+    ep, eD, em = ref.rank_forward(g["Q"], last, depth=5, output_D_embedding=True)
+    gp, gD, gm = r.rank_forward(g["Q"], last, depth=5, output_D_embedding=True)
+    assert gp == ep and torch.equal(gm.cpu(), em)
+    torch.testing.assert_close(gD.cpu(), eD, rtol=0, atol=0)
     with pytest.raises(RuntimeError):
         r.rank_forward(g["Q"], list(range(64)), depth=64, output_D_embedding=True)   # spans several buckets
+    # the reference cat()s the D of ALL candidates (:132), so it fails whenever they span several buckets -- also when the
+    # top-`depth` docs alone would share one
+    other = [i for i in range(64) if int(pad[i]) != S][:1]
+    with pytest.raises(RuntimeError):
+        ref.rank_forward(g["Q"], same + other, depth=1, output_D_embedding=True)
+    with pytest.raises(RuntimeError):
+        r.rank_forward(g["Q"], same + other, depth=1, output_D_embedding=True)
 
 
 def test_rank_forward_asserts(ca, golden):

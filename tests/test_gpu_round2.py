@@ -193,7 +193,7 @@ def test_rank_forward_input_forms_and_threads(ca, golden):
     [t.join() for t in ths]
     assert not errors, errors
     # the CPython glue (csrc/fastrank.c) and the ctypes path make the same library call: identical lists; a list the
-    # glue refuses (numpy integers) takes the general path; out-of-range pids are an error on both
+    # glue refuses (numpy integers) takes the general path (out-of-range pids: test_rank_forward_bad_pids_raise_like_the_reference)
     from colbert_amd import ranker as rk
     assert rk._fastrank is not None
     fast = r.rank_forward(Q, pids, depth=100)

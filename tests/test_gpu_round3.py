@@ -146,3 +146,93 @@ def test_sharded_local_topk_uses_counted_rows(ca):
     p0, s0 = r.topk(r.score_candidates(Q, loc), gp, 100)
     assert torch.equal(p0.cpu(), p1.cpu()) and torch.equal(s0.cpu(), s1.cpu())
     assert int((p1 >= 0).sum()) > 0 and bool(((p1 < 0) | ((p1 >= lo) & (p1 < hi))).all())
+
+
+# ------------------------------------------------------------------------------------------------------
+# rank_forward's failure modes: `self.doclens[pids]`, colbert_ranker.py:88
+# ------------------------------------------------------------------------------------------------------
+def test_rank_forward_bad_pids_raise_like_the_reference(ca):
+    """A pid >= n_docs or < -n_docs raises IndexError where the reference's `self.doclens[pids]` does (the oracle's
+    restatement raises the same), for every input form and on both host paths (CPython glue / ctypes); nothing is
+    returned with a -inf score.  A negative pid in [-n_docs, -1] indexes from the end as torch indexing does, and the
+    caller's own value comes back (colbert_ranker.py:129)."""
+    from colbert_amd import ranker as rk
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(23)
+    ndocs = 200
+    doclens = torch.randint(1, 120, (ndocs,), generator=gen).tolist()
+    emb = nrm(gen, sum(doclens), 128).half()
+    ref = RefRanker([emb], [doclens], dim=128)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=128)
+    Q = nrm(gen, 32, 128).unsqueeze(0).permute(0, 2, 1)
+    good = torch.randperm(ndocs, generator=gen)[:50].tolist()
+    for bad in (ndocs, ndocs + 12345, -ndocs - 1, 2 ** 40):
+        pids = good[:20] + [bad] + good[20:]
+        with pytest.raises(IndexError):
+            ref.rank_forward(Q, pids, depth=10)
+        forms = [pids, torch.tensor(pids), torch.tensor(pids).cuda(), [np.int64(p) for p in pids]]
+        for form in forms:
+            with pytest.raises(IndexError, match="out of bounds for dimension 0 with size 200"):
+                r.rank_forward(Q, form, depth=10)
+        saved, rk._fastrank = rk._fastrank, None
+        try:
+            with pytest.raises(IndexError):
+                r.rank_forward(Q, pids, depth=10)
+        finally:
+            rk._fastrank = saved
+        with pytest.raises(IndexError):
+            r.rank_forward(Q, pids, depth=10, output_D_embedding=True)
+    # negative pids wrap: doc ndocs + p is scored, p itself is returned
+    neg = good[:10] + [-1, -ndocs, -7] + good[10:30]
+    pos = [p if p >= 0 else p + ndocs for p in neg]
+    ep, es = ref.rank_forward(Q, pos, depth=33)
+    for form in (neg, torch.tensor(neg), torch.tensor(neg).cuda()):
+        gp, gs = r.rank_forward(Q, form, depth=33)
+        np.testing.assert_allclose(np.array(gs), np.array(es), rtol=0, atol=ATOL32)
+        assert [p if p >= 0 else p + ndocs for p in gp] == ep and set(gp) == set(neg)
+    # the good list still works after the failures (no state was left behind in the per-thread workspace)
+    assert r.rank_forward(Q, good, depth=10)[0] == ref.rank_forward(Q, good, depth=10)[0]
+
+
+# ------------------------------------------------------------------------------------------------------
+# the reference's default deployment shape: dim 768 (proj_conf/dense.yaml:6-8), fp16 index (encoder.py:175), ragged docs
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float16, torch.float32])
+def test_ragged_rerank_768_golden(ca, golden, dtype):
+    g = golden("ragged_rerank_768")
+    parts = [g["part0"], g["part1"]]
+    pdl = [g["doclens0"].tolist(), g["doclens1"].tolist()]
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=768, index_dtype=dtype)
+    assert r.strides == g["strides"].tolist()
+    assert torch.equal(r.d_pad_len.cpu().long(), g["pad_len"])
+    pids = g["pids"]
+    for key, exp in (("Q", "expected_scores"), ("Q_neg", "expected_scores_neg")):
+        sc = r.score_candidates(g[key].permute(0, 2, 1), pids.view(1, -1))
+        torch.testing.assert_close(sc.cpu()[0], g[exp], rtol=0, atol=ATOL32)        # fp32 query on an fp16-exact index: fp32 tolerance
+    tp, ts = r.rank_forward(g["Q"], pids.tolist(), depth=10)
+    assert tp == g["top10_pids"].tolist()
+    np.testing.assert_allclose(ts, g["top10_scores"].numpy(), rtol=0, atol=ATOL32)
+
+
+def test_ragged_768_fp16_batch_vs_oracle(ca):
+    """A bigger ragged 768-dim fp16 index (doclens 1..384, the reference's doc_maxlen) scored in batches against the
+    oracle's float64 closed form: every candidate of every query, incl. counted rows (static-grid fallback for h != 128)."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(41)
+    ndocs, h = 120, 768
+    doclens = (torch.randn(ndocs, generator=gen) * 80 + 200).round().clamp(1, 384).long().tolist()
+    doclens[:4] = [384, 1, 383, 33]
+    emb = nrm(gen, sum(doclens), h).half()
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=torch.float16)
+    nq, ncand = 5, 60
+    Q = nrm(gen, nq, 32, h)
+    cand = torch.stack([torch.randperm(ndocs, generator=gen)[:ncand] for _ in range(nq)])
+    sc = r.score_candidates(Q, cand.cuda()).cpu()
+    for qi in range(nq):
+        exp = ragged_scores_f64(emb, r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi], cand[qi].tolist())
+        np.testing.assert_allclose(sc[qi].numpy(), exp, rtol=0, atol=ATOL32)
+    # 16-bit query handed over in the index's own type: the 16-bit-input tolerance
+    sc16 = r.score_candidates(Q.half(), cand.cuda()).cpu()
+    for qi in range(nq):
+        exp = ragged_scores_f64(emb, r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi].half().float(), cand[qi].tolist())
+        np.testing.assert_allclose(sc16[qi].numpy(), exp, rtol=0, atol=ATOL16)

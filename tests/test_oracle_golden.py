@@ -70,6 +70,25 @@ def test_ragged_rerank_golden(golden):
     assert floored.any() and (~floored).any()
 
 
+def test_ragged_rerank_768_golden(golden):
+    """The reference's default deployment shape (dim 768, fp16 index, ragged docs): oracle restatement + closed form
+    against the fixture the imported reference wrote (tests/golden/make_golden.py, section 8)."""
+    g = golden("ragged_rerank_768")
+    r = RefRanker([g["part0"], g["part1"]], [g["doclens0"].tolist(), g["doclens1"].tolist()], dim=768)
+    n = len(r.doclens)
+    assert r.strides == g["strides"].tolist() and torch.equal(r.bucket_strides(list(range(n))), g["pad_len"])
+    pids = g["pids"].tolist()
+    for key, exp in (("Q", "expected_scores"), ("Q_neg", "expected_scores_neg")):
+        torch.testing.assert_close(r.all_scores(g[key], pids), g[exp], rtol=0, atol=1e-5)
+        f64 = ragged_scores_f64(r.tensor, r.doclens, r.doclens_pfxsum, g["pad_len"], g[key][0].permute(1, 0), pids)
+        np.testing.assert_allclose(g[exp].numpy(), f64, rtol=0, atol=3e-5)
+    tp, ts = r.rank_forward(g["Q"], pids, depth=10)
+    assert tp == g["top10_pids"].tolist()
+    np.testing.assert_allclose(ts, g["top10_scores"].numpy(), rtol=0, atol=1e-5)
+    floored = g["pad_len"] > torch.cat([g["doclens0"], g["doclens1"]])
+    assert floored.any() and (~floored).any()
+
+
 def test_ragged_closed_form_equals_bucketed(golden):
     """The fused kernel's definition (real tokens + analytic 0-floor) equals the reference's bucket/pad/mask."""
     g = golden("ragged_rerank_64")
