@@ -31,7 +31,25 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
     return MAXSIM_ERANGE;
   } else {
     if constexpr (QB == 1) {
+#ifdef MAXSIM_DIAG
+      if constexpr (MODE == MODE_RERANK) {  // diagnostic: MAXSIM_BIGH_SHAPE = waves * 10 + sub-tiles per wave
+        const int shape = MAXSIM_KNOB("MAXSIM_BIGH_SHAPE", 0);
+        if (shape == 81 && avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
+        if (shape == 42 && avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
+        if (shape == 41 && avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB>, 4, 1);
+        if (shape == 121 && avail >= 12 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 12, 1, AM, QB>, 12, 1);
+        if (shape == 141 && avail >= 14 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 14, 1, AM, QB>, 14, 1);
+        if (shape == 161 && avail >= 16 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 16, 1, AM, QB>, 16, 1);
+        if (shape == 62 && avail >= 6 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 6, 2, AM, QB>, 6, 2);
+      }
+#endif
       if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
+      // A two-piece query image (an fp32 query on a 16-bit index: the reference's deployment, dim 768 fp16 -> 96 KiB)
+      // leaves 64 KiB for the rings: eight waves with one sub-tile each beat four waves with two -- the same bytes in
+      // flight, but twice the matrix work per byte has twice the waves to hide behind (ragged dim-768 fp16 docs:
+      // 13.45 -> 11.81 ms, 0.73 -> 0.83 of peak; with a one-piece image, e.g. C5, the two shapes measure the same)
+      if constexpr (MODE == MODE_RERANK && NPQ == 2)
+        if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
       if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
     } else {  // several queries per workgroup: the matrix work per sub-tile is QB x longer, one sub-tile ahead suffices
       if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
