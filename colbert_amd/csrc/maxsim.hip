@@ -47,6 +47,9 @@ int for_query_slices(Params& p, F&& launch) {
   return MAXSIM_OK;
 }
 constexpr int MAX_LQ_SLICED = 1024;
+#ifdef MAXSIM_STAMP
+const void* g_stamp_buffer = nullptr;  // timing builds: where the stream kernel's waves write their phase stamps
+#endif
 
 template <int MODE>
 int launch_generic(Params& p, int dt, hipStream_t st) {
@@ -256,6 +259,9 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
   p.nq = nq; p.ncand = ncand; p.Lq = Lq; p.h = h;
   p.scores = scores;
   p.mask_dtype = MAXSIM_MASK_NONE;
+#ifdef MAXSIM_STAMP
+  p.d_mask = g_stamp_buffer;  // timing builds: per-wave phase stamps (maxsim_stream.h)
+#endif
   const bool aligned = (((uintptr_t)Q | (uintptr_t)iv.index) & 15) == 0;  // the streaming kernels move 16-byte pieces
   const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
   // counted rows (doc shards, ANN lists): the device builds a dense list of wave items and a fixed grid walks it.  Short
@@ -311,6 +317,10 @@ int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, co
   if (!iv) return MAXSIM_EINVAL;
   return rerank_impl(*iv, Q, q_dtype, q_len, q_mask, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream);
 }
+
+#ifdef MAXSIM_STAMP
+void maxsim_diag_set_stamp_buffer(const void* p) { g_stamp_buffer = p; }
+#endif
 
 int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
                           const uint8_t* q_mask, const int64_t* cand_pids, const int32_t* cand_count, int nq, int ncand,
@@ -403,7 +413,10 @@ int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype,
   const int k = depth < n ? depth : n;
   int rc = rerank_impl(*iv, Q, q_dtype, nullptr, nullptr, pids, 1, n, Lq, scores, st);
   if (rc != MAXSIM_OK) return rc;
-  // colbert_ranker.py:128-130.  Short lists: the counting kernel, whose last workgroup stores a ticket to done_flag
+  // colbert_ranker.py:128-130.  Short lists: the counting kernel, whose last workgroup stores a ticket to done_flag.
+  // (Running that ranking at the END OF THE RERANK LAUNCH instead -- its first n / 16 workgroups waiting in-kernel for the
+  //  launch's scores -- was built and measured: the GPU span of a call grew by 2-4 us and the call took as long as with
+  //  two launches, tools/attic/README.md "fused top-k"; the second launch overlaps the first kernel and costs nothing.)
   const bool poll = sync && done_flag && n <= 2048 && MAXSIM_KNOB("MAXSIM_POLL", 1) != 0;
   static std::atomic<uint32_t> tickets{0};
   uint32_t ticket = ++tickets;

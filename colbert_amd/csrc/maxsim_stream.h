@@ -550,12 +550,21 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   constexpr int ROWB = T::ROWB, TILE = T::TILE, NDMA = T::NDMA, RPD = T::RPD, LPR = T::LPR, NRD = T::NRD, NP = T::NP;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
+  // a finished score (passes after the first of a query longer than 32 tokens add to the cell)
+  auto put_score = [&](float* cell, float v) __attribute__((always_inline)) { *cell = (p.accum ? *cell : 0.0f) + v; };
   // unsplit: every wave has its own docs.  SPLITK: `split` consecutive waves form a team that shares dpwv docs; wave
   // `part` of the team streams the part-th slice of each doc (slices are whole 32-row tiles, cut as evenly as possible)
   const int split = SPLITK ? p.split : 1;
   const int team = SPLITK ? wave / split : wave, part = SPLITK ? wave - team * split : 0;
   // one wave item: candidates [c_begin, c_begin + ndoc) of query qi
   auto wave_item = [&](const int qi, const int c_begin, const int ndoc) __attribute__((always_inline)) {
+#ifdef MAXSIM_STAMP  // timing builds only (tools/probe_timeline.py): 100 MHz stamps of this wave's phases -> p.d_mask
+  uint64_t stamp[6];
+  stamp[0] = __builtin_amdgcn_s_memrealtime();
+#define MAXSIM_STAMP_AT(i) stamp[i] = __builtin_amdgcn_s_memrealtime()
+#else
+#define MAXSIM_STAMP_AT(i)
+#endif
   DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
   if constexpr (SPLITK) {
     const int per = (((dl.len + 31) >> 5) + split - 1) / split * 32;  // rows per slice
@@ -574,6 +583,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   Cursor F, C;
   F.init(dl, ndoc);
   C = F;
+  MAXSIM_STAMP_AT(1);  // descriptors are here
 
   auto issue_tile = [&](int buf, const TileMap& t) __attribute__((always_inline)) {
     if (ABLATE == 2) return;
@@ -584,20 +594,29 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   //      first fetch) -----------------------------------------------------------------------
   int nissued = 0, nconsumed = 0;
   bool prev_issued = false;
+  auto prologue = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const TileMap t = fill_tile(F, dl, r);
-    if (t.kind != 0) {
-      issue_tile(j, t);
-      ++nissued;
+    for (int j = 0; j < NT; ++j) {
+      const TileMap t = fill_tile(F, dl, r);
+      if (t.kind != 0) {
+        issue_tile(j, t);
+        ++nissued;
+      }
+      prev_issued = t.kind != 0;
     }
-    prev_issued = t.kind != 0;
-  }
+  };
+  // QFIRST (the split form: small launches of a 16-bit index, two tiles per wave in the ring): the query goes to registers
+  // BEFORE the first fetches.  Behind them its loads sit at the end of the in-order vmcnt queue, so the wave cannot start
+  // on tile 0 before BOTH prologue tiles have landed -- in a one-query launch every wave asks for its first two tiles at
+  // once (2000 waves x 16 KiB), that burst takes ~8 us to deliver, and nothing is in flight when it ends (stamped:
+  // tools/probe_timeline.py).  In front of them the query costs one exposed L2 / HBM latency (~1 us) and the stream never stops.
+  constexpr bool QFIRST = SPLITK;
+  if constexpr (!QFIRST) prologue();
   if (!SPLITK && nissued == 0) {  // (the split form meets at a workgroup barrier below: no early exit)
     // nothing to stream: every slot of this wave is a padding slot (-inf) or an empty doc (0) -- e.g. the tail of a
     // doc-sharded candidate row (maxsim_shard_candidates).  Retire before the 16 KiB query tile is fetched.
     float* const srow0 = p.scores + (int64_t)qi * p.ncand + c_begin;
-    if (lane < ndoc) srow0[lane] = (p.accum ? srow0[lane] : 0.0f) + ((dl.flags & 3) == 1 ? 0.0f : NEG_INF);
+    if (lane < ndoc) put_score(srow0 + lane, (dl.flags & 3) == 1 ? 0.0f : NEG_INF);
     return;
   }
 
@@ -607,6 +626,34 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   constexpr bool F16Q = (DT == MAXSIM_F16 || DT == F32S);  // query split into fp16 hi + 2^-11 lo
   f32x4 qv[DT == MAXSIM_F32 ? 16 : 1];
   u32x4 qp[DT == MAXSIM_F32 ? 1 : NP][DT == MAXSIM_F32 ? 1 : 8];
+  // QSTAGE (small launches: every workgroup of the launch wants the SAME one or few query tiles at the same moment): the
+  // workgroup fetches its query's 32 x 128 fp32 image ONCE, in whole cache lines, into the still empty rings, and each
+  // wave takes its B-operand layout from LDS.  With every wave gathering its own 16 KiB from global memory a one-query
+  // launch sends 2000 waves x 256 line requests at the same 128 lines: the L2 channels that hold them serialise the
+  // requests (stamped: 4-7 us from "descriptors there" to "query in registers"; 16x fewer requests this way).
+  constexpr bool QSTAGE = QFIRST;
+  constexpr int QS_ROW = 132;  // floats per staged row: 512 B + 16 B of padding (bank spread of the 16 token rows)
+  const float* const lds_q = (const float*)lds;
+  if constexpr (QSTAGE) {
+    int qlen0 = p.Lq;
+    if (MODE == MODE_RERANK && p.q_len) qlen0 = min(qlen0, p.q_len[qi]);
+    const bool qf32s = p.q_dtype == MAXSIM_F32;
+    for (int c = threadIdx.x; c < 32 * 32; c += WAVES * 64) {
+      const int row = c >> 5, chunk = c & 31;
+      const int tokq = p.q_tok0 + row;
+      const bool lv = q_token_live<MODE>(p, qi, tokq, qlen0);
+      const int64_t src = ((int64_t)qi * p.Lq + (lv ? tokq : 0)) * 128 + 4 * chunk;
+      f32x4 v;
+      if (qf32s) {
+        v = *(const f32x4*)((const float*)p.Q + src);
+      } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, src + t);
+      }
+      *(f32x4*)((float*)lds + row * QS_ROW + 4 * chunk) = lv ? v : (f32x4)(0.0f);
+    }
+    __syncthreads();
+  }
   {
     int qlen = p.Lq;
     if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
@@ -626,6 +673,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           f32x4 v;
+          if constexpr (QSTAGE) {  // staged rows are already zero where the token is not live
+            qv[8 * cb + j] = *(const f32x4*)(lds_q + (16 * cb + n16) * QS_ROW + 16 * j + 4 * kq);
+            continue;
+          }
           if (qf32) {
             v = *(const f32x4*)((const float*)p.Q + qo + 16 * j + 4 * kq);
           } else {
@@ -665,7 +716,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
           e0 = ((int64_t)qi * p.Lq + (lv ? tok16 : 0)) * 128 + 8 * (4 * (i & 3) + (lane >> 4));
         }
         float q[8];
-        if (qf32) {
+        if constexpr (QSTAGE && QT == QT_2X16) {
+          const float* const ql = lds_q + (16 * (i >> 2) + (lane & 15)) * QS_ROW + 8 * (4 * (i & 3) + (lane >> 4));
+          const f32x4 v0 = *(const f32x4*)ql, v1 = *(const f32x4*)(ql + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { q[j] = v0[j]; q[4 + j] = v1[j]; }
+          lv = true;
+        } else if (qf32) {
           const f32x4 v0 = *(const f32x4*)((const float*)p.Q + e0);
           const f32x4 v1 = *(const f32x4*)((const float*)p.Q + e0 + 4);
 #pragma unroll
@@ -708,6 +765,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
     }
   }
+  if constexpr (QFIRST) {
+    wait_vmcnt<0>();  // the query is in registers: from here on only tile fetches count in vmcnt
+    if constexpr (QSTAGE) {
+      wait_lgkmcnt0();
+      __syncthreads();  // every wave has taken its operands: the rings may be overwritten
+    }
+    prologue();
+  }
 
   Reducer red;
   Reducer16 red16;
@@ -720,10 +785,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   if constexpr (SPLITK) red2.part = parked + wave * (SPLIT_MAX_DOCS * 32);
   int buf = 0;
 
+  MAXSIM_STAMP_AT(2);  // first fetches issued, query in registers
   while (nconsumed < nissued) {
     __builtin_amdgcn_s_setprio(0);
     // tiles c+1 .. c+NT-1 were issued after this one iff the previous step issued
     if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
+#ifdef MAXSIM_STAMP
+    if (nconsumed == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();  // the first tile has arrived
+#endif
     const char* tl = wlds + buf * TILE + rdbase;
     u32x4 a[NRD];
 #pragma unroll
@@ -998,7 +1067,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     red.reduce_tile(sv, C, dl, lane);
     ++nconsumed;
   }
+  MAXSIM_STAMP_AT(4);  // last tile contracted and reduced
   float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
+#ifdef MAXSIM_STAMP
+  if (p.d_mask && lane == 0) {
+    uint64_t* const sb = (uint64_t*)p.d_mask + ((int64_t)blockIdx.x * WAVES + wave) * 8;
+    sb[0] = stamp[0]; sb[1] = stamp[1]; sb[2] = stamp[2]; sb[3] = stamp[3]; sb[4] = stamp[4];
+    sb[5] = (uint64_t)nissued;
+    sb[6] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
   if constexpr (SPLITK) {
     red2.drain(C, dl, lane);
     __syncthreads();  // every slice of the workgroup's docs is parked
@@ -1018,17 +1096,17 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
         }
         mine = (lane == j) ? sc : mine;
       }
-      if (lane < ndoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + mine;
+      if (lane < ndoc) put_score(srow + lane, mine);
     }
   } else if constexpr (QT == QT_2X16) {
     red2.drain(C, dl, lane);
-    if (lane < red2.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red2.myscore;
+    if (lane < red2.jdoc) put_score(srow + lane, red2.myscore);
   } else if constexpr (QT == 16) {
     red16.drain(C, dl, lane);
-    if (lane < red16.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red16.myscore;
+    if (lane < red16.jdoc) put_score(srow + lane, red16.myscore);
   } else {
     red.drain(C, dl, lane);
-    if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
+    if (lane < red.jdoc) put_score(srow + lane, red.myscore);
   }
   };  // wave_item
   if constexpr (LIST) {

@@ -236,3 +236,63 @@ def test_ragged_768_fp16_batch_vs_oracle(ca):
     for qi in range(nq):
         exp = ragged_scores_f64(emb, r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi].half().float(), cand[qi].tolist())
         np.testing.assert_allclose(sc16[qi].numpy(), exp, rtol=0, atol=ATOL16)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the online call (maxsim_rank_forward: rerank + counting top-k, polled completion) against the batched entry points
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,Lq", [(torch.float32, 32), (torch.float32, 9), (torch.float16, 32), (torch.bfloat16, 32)])
+def test_rank_forward_equals_batched_entry_points(ca, dtype, Lq):
+    """rank_forward (one C call: the small-launch forms of the rerank kernel -- docs of a 16-bit index split over waves,
+    the query staged through LDS -- then the counting top-k whose last workgroup stores the polled completion word) returns
+    exactly what the batched entry points return for the same list, for list lengths around the ranking-group size (16), the
+    reference's ~1000, the counting kernel's limit (2048) and beyond (the sort kernel), call after call on one workspace (its
+    counter returns to zero), with depth below, at and above the list length."""
+    gen = torch.Generator().manual_seed(3)
+    ndocs, h = 4000, 128
+    doclens = torch.randint(100, 301, (ndocs,), generator=gen).tolist()            # long enough for the split form (fp16 / bf16)
+    emb = nrm(gen, sum(doclens), h).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=dtype)
+    q = nrm(gen, Lq, h)
+    Q = q.unsqueeze(0).permute(0, 2, 1)
+    for n in (1, 2, 15, 16, 17, 100, 333, 1000, 1000, 2047, 2048, 2049, 3000, 7):
+        pids = torch.randint(0, ndocs, (n,), generator=gen).tolist()                # duplicates allowed: equal scores, tie order by position
+        for depth in (1, 10, n, n + 5):
+            k = min(depth, n)
+            gp, gs = r.rank_forward(Q, pids, depth=depth)
+            cand = torch.tensor(pids).view(1, -1).cuda()
+            tp, ts = r.topk(r.score_candidates(q.unsqueeze(0), cand), cand, k)
+            assert gp == tp[0].tolist() and gs == ts[0].tolist(), (n, depth)
+
+
+def test_rank_forward_concurrent_threads_and_streams(ca):
+    """Three host threads, each with its own workspace (counter, pinned buffers, completion word) and its own stream, issue
+    calls at the same time: one call's completion must not be confused with another's."""
+    import threading
+    gen = torch.Generator().manual_seed(4)
+    ndocs, h = 3000, 128
+    doclens = torch.randint(60, 181, (ndocs,), generator=gen).tolist()
+    emb = nrm(gen, sum(doclens), h)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=torch.float32)
+    q = nrm(gen, 32, h)
+    Q = q.unsqueeze(0).permute(0, 2, 1).cuda()
+    lists = [torch.randint(0, ndocs, (1000,), generator=gen).tolist() for _ in range(8)]
+    exp = []
+    for pl in lists:
+        cand = torch.tensor(pl).view(1, -1).cuda()
+        tp, ts = r.topk(r.score_candidates(q.unsqueeze(0), cand), cand, 100)
+        exp.append((tp[0].tolist(), ts[0].tolist()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(tid):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            for it in range(60):
+                i = (it + tid) % len(lists)
+                if r.rank_forward(Q, lists[i], depth=100) != exp[i]:
+                    errors.append((tid, it))
+    ths = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert not errors, errors[:5]

@@ -30,7 +30,7 @@ __device__ __forceinline__ float unorderable(uint32_t k) {
 // =============================================================================================
 constexpr int TOPK_CAND_PER_WG = 16;
 
-// The ranking step of k_topk_count: `keys` (LDS, n16 entries, 0 past the n real
+// The ranking step shared by k_topk_count and the fused rank_forward kernels: `keys` (LDS, n16 entries, 0 past the n real
 // ones) -> the 16 candidates of group g each count the keys above their own and, when that rank is < k, write
 // (score, pid) to output slot `rank`.  COHERENT: the host may read the outputs while the kernel is still running
 // (system-scope write-through stores).  256 threads.
@@ -63,7 +63,89 @@ __device__ __forceinline__ void topk_rank_group(const uint64_t* keys, int n, int
   }
 }
 
-__global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ scores, const int64_t* __restrict__ pids,
+// =============================================================================================
+// FUSED rank_forward (one query, n <= 2048 candidates, the reference's online call): the top-k runs in the SAME launch
+// as the rerank.  Called by every workgroup of a rerank kernel after its waves have stored their scores with agent-scope
+// (write-through) stores.  Every workgroup announces itself by storing the call's ticket to ITS OWN word of an arrival
+// table; the first ceil(n / 16) workgroups -- the ranking groups of k_topk_count -- then wait until every word of the
+// table holds the ticket, pull the score row into LDS with agent-scope loads and rank their 16 candidates; the last of
+// them to finish (a two-level counter tree) stores the ticket to the host's completion word.  Against a second launch
+// this saves the kernel boundary, the second dispatch and the top-k kernel's ramp.
+// No atomics on the way in: 250 workgroups adding to ONE counter serialise at ~70 ns each (measured: the first fused
+// build, with one arrival counter, took 15-20 us LONGER than two launches); plain stores to distinct words do not, and the
+// table needs no reset (a new call has a new ticket).  The completion tree keeps every counter to <= 8 adds.
+// The wait cannot deadlock the launch: at most 128 workgroups spin and they are the first dispatched, so every other
+// workgroup finds a slot on the chip whatever they do; the spin is bounded all the same -- when it runs out (a GPU shared
+// with something that holds every slot for tens of milliseconds) the group skips its ranking, status word done_flag[1]
+// is set to 1 and the host runs the top-k as a second launch.
+// Workspace header (device memory, zero before the first call, maxsim_rank_forward_workspace_bytes):
+//   [0, 64) the two-launch path's counter | 128 (1 + i): leaf counter i (i < 16) | 128 * 17: root counter |
+//   [4096, 8192) arrival table, one uint32 per workgroup | [8192, ...) the score row
+// =============================================================================================
+constexpr int FUSED_SPIN_LIMIT = 1 << 16;  // x ~1 us per poll of the arrival table
+constexpr int FUSED_HEADER_BYTES = 8192, FUSED_ARRIVE_OFF = 4096, FUSED_MAX_WGS = 1024;
+__device__ __forceinline__ void fused_topk(const float* scores, const int64_t* pids, int n, int k, float* out_s,
+                                           int64_t* out_p, char* header, uint32_t* done_flag, uint32_t ticket,
+                                           uint64_t* keys /* LDS: 2048 entries */) {
+  const int tid = threadIdx.x;
+  const int groups = (n + TOPK_CAND_PER_WG - 1) / TOPK_CAND_PER_WG;
+  uint32_t* const arrive = (uint32_t*)(header + FUSED_ARRIVE_OFF);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's score stores are acknowledged
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(arrive + blockIdx.x, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int g = (int)blockIdx.x;
+  if (g >= groups) return;
+  bool ok = false;
+  for (int spins = 0; spins < FUSED_SPIN_LIMIT; ++spins) {
+    int here = 1;
+    for (int i = tid; i < (int)gridDim.x; i += 256)
+      here &= __hip_atomic_load(arrive + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ticket ? 1 : 0;
+    if (__syncthreads_and(here)) {
+      ok = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (ok) {
+    const int n16 = (n + 15) & ~15;
+    for (int i = tid; i < n16; i += 256) {
+      uint64_t key = 0ull;  // 0 < every real key
+      if (i < n) {
+        const float sc = __hip_atomic_load(scores + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        key = ((uint64_t)orderable(sc) << 32) | (uint32_t)(~(uint32_t)i);
+      }
+      keys[i] = key;
+    }
+    __syncthreads();
+    topk_rank_group<true>(keys, n, n16, g, k, pids, out_s, out_p);
+    if (g == 0)  // slots [n, k) (k > n): (-inf, -1)
+      for (int i = n + tid; i < k; i += 256) {
+        __hip_atomic_store(out_s + i, NEG_INF, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(out_p + i, (int64_t)-1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+  } else if (tid == 0) {
+    __hip_atomic_store(done_flag + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's outputs are acknowledged ...
+  __syncthreads();                                   // ... and so are the workgroup's
+  if (tid == 0) {
+    // completion tree: leaves of 8 ranking groups; whoever fills a leaf zeroes it and adds to the root; whoever fills the
+    // root zeroes it and tells the host.  Exactly one workgroup gets there, after every output of the launch is written.
+    const int leaf = g >> 3, nleaves = (groups + 7) >> 3;
+    const int leaf_size = min(8, groups - 8 * leaf);
+    int32_t* const lc = (int32_t*)(header + 128 * (1 + leaf));
+    int32_t* const root = (int32_t*)(header + 128 * 17);
+    if (__hip_atomic_fetch_add(lc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == leaf_size - 1) {
+      __hip_atomic_store(lc, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (__hip_atomic_fetch_add(root, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nleaves - 1) {
+        __hip_atomic_store(root, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(done_flag, ticket, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ scores, const int64_t* __restrict__ pids,
                                                     int ncand, int k, float* __restrict__ out_s,
                                                     int64_t* __restrict__ out_p, int groups, int32_t* counter,
                                                     uint32_t* done_flag, uint32_t ticket,
@@ -108,7 +190,7 @@ __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ sc
 // =============================================================================================
 // Long lists (2048 < ncand <= 16384 = the reference's BSIZE): bitonic sort of the keys in LDS, one workgroup per query.
 // =============================================================================================
-__global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores, const int64_t* __restrict__ pids,
+static __global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores, const int64_t* __restrict__ pids,
                                                int ncand, int k, int P, float* __restrict__ out_s,
                                                int64_t* __restrict__ out_p) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -148,7 +230,7 @@ __global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores,
   }
 }
 
-__global__ void k_fill(float* out, int64_t n, float v) {
+static __global__ void k_fill(float* out, int64_t n, float v) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = v;
 }
