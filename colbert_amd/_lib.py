@@ -18,7 +18,7 @@ SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_re
            "maxsim_embedding_ids_to_pids", "maxsim_score_dense_fwd", "maxsim_score_dense_bwd",
            "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_rank_forward_workspace_bytes", "maxsim_doc_table_bytes",
            "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel", "maxsim_worklist_bytes",
-           "maxsim_rerank_counted", "maxsim_topk_counted", "maxsim_hbm_read_probe",
+           "maxsim_rerank_counted", "maxsim_topk_counted", "maxsim_hbm_read_probe", "maxsim_hbm_read_probe_scattered",
            "maxsim_host_alloc_coherent", "maxsim_host_free")
 
 
@@ -26,7 +26,8 @@ class IndexView(ctypes.Structure):
     """``maxsim_index_view`` (include/maxsim.h)."""
     _fields_ = [("index", ctypes.c_void_p), ("index_dtype", ctypes.c_int32), ("h", ctypes.c_int32),
                 ("n_tokens", ctypes.c_int64), ("tok_offsets", ctypes.c_void_p), ("doclens", ctypes.c_void_p),
-                ("pad_len", ctypes.c_void_p), ("n_docs", ctypes.c_int64), ("doc_table", ctypes.c_void_p)]
+                ("pad_len", ctypes.c_void_p), ("n_docs", ctypes.c_int64), ("doc_table", ctypes.c_void_p),
+                ("uniform_len", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class MaxSimError(RuntimeError):
@@ -88,6 +89,8 @@ def _load():
     lib.maxsim_host_free.argtypes = [vp]
     lib.maxsim_hbm_read_probe.restype = i32
     lib.maxsim_hbm_read_probe.argtypes = [vp, i64, i32, vp, vp]
+    lib.maxsim_hbm_read_probe_scattered.restype = i32
+    lib.maxsim_hbm_read_probe_scattered.argtypes = [vp, i64, i32, i32, i64, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
     return lib

@@ -250,6 +250,7 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
   p.doclens = iv.doclens;
   p.pad_len = iv.pad_len;
   p.doc_table = iv.doc_table;
+  p.uniform_len = iv.uniform_len;
   p.n_docs = n_docs;
   p.Q = Q;
   p.q_dtype = q_dtype;
@@ -450,6 +451,25 @@ void* maxsim_host_alloc_coherent(int64_t bytes) {
 
 void maxsim_host_free(void* p) {
   if (p) (void)hipHostFree(p);
+}
+
+int maxsim_hbm_read_probe_scattered(const void* buf, int64_t bytes, int granule, int variant, int64_t read_bytes, void* stream) {
+  if (!buf || bytes < 0 || read_bytes < 0 || ((uintptr_t)buf & 15) != 0) return MAXSIM_EINVAL;
+  if (granule < 1024 || (granule & (granule - 1)) != 0 || granule > (1 << 20) || variant < 0 || variant > 3) return MAXSIM_EINVAL;
+  const int64_t per_wave = 256 * 1024;
+  int64_t ngran = 1;  // granules of the buffer, rounded down to a power of two (the kernel masks a hash)
+  while (2 * ngran * granule <= bytes && ngran < (1LL << 31)) ngran *= 2;
+  const int64_t wgs = read_bytes / (4 * per_wave);
+  if (wgs == 0 || ngran * granule > bytes) return MAXSIM_OK;
+  if (wgs > 0x7fffffffLL) return MAXSIM_ERANGE;
+  hipStream_t st = (hipStream_t)stream;
+  switch (variant) {
+    case 0: hipLaunchKernelGGL((k_read_probe_scatter<16384, 1>), dim3((unsigned)wgs), dim3(256), 4 * 16384, st, (const char*)buf, per_wave, ngran, granule); break;
+    case 1: hipLaunchKernelGGL((k_read_probe_scatter<8192, 2>), dim3((unsigned)wgs), dim3(256), 4 * 2 * 8192, st, (const char*)buf, per_wave, ngran, granule); break;
+    case 2: hipLaunchKernelGGL((k_read_probe_scatter<8192, 1>), dim3((unsigned)wgs), dim3(256), 4 * 8192, st, (const char*)buf, per_wave, ngran, granule); break;
+    default: hipLaunchKernelGGL((k_read_probe_scatter<8192, 1>), dim3((unsigned)(wgs / 2)), dim3(256), 4 * 8192, st, (const char*)buf, 2 * per_wave, ngran, granule); break;
+  }
+  return check_launch();
 }
 
 int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* bytes_read, void* stream) {

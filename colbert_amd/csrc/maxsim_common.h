@@ -54,6 +54,7 @@ struct Params {
   // dense work list (maxsim_worklist.h; counted candidate rows -- doc shards, ANN lists): NULL, or the device-built list of
   // (query, first slot, docs) wave items the LIST kernels walk instead of the static (query, chunk) grid
   const void* worklist;
+  int uniform_len;  // host side only (launch choice): > 0 = every doc has exactly this many tokens, none is padded
 };
 
 // Kernel arguments: the read-only tables are passed as individual `const __restrict__` pointers (not inside

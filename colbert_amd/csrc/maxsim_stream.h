@@ -1323,4 +1323,145 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
   if (lane < red.jdoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + red.myscore;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Uniform short docs: EVERY doc of the index has exactly L tokens, L = 4, 8 or 16 (maxsim_index_view.uniform_len).  That is
+// the reference's multi-view configuration by construction -- `enable_multiview` keeps d_view viewer tokens per doc
+// (proj_conf/dense.yaml:31-32: d_view = 8) -- and BASELINE configs[3].
+// A launch over such docs is not bound by bytes alone: with the general half-tile kernel the wave spends ~230 scalar / vector
+// instructions per 8 KiB tile on walking documents of unknown length (cursor, row map, two-segment addresses, masked
+// maxima, one finish per doc) next to its 32 MFMAs, four waves per SIMD: with the fetch switched off the launch still takes
+// 0.111 ms of its 0.183 (MAXSIM_VARIANT=2 in a diagnostic build).  With the length a compile-time constant all of that is
+// straight-line code: a tile is DPT = 16 / L whole docs, its rows come from DPT readlanes, the source address of DMA
+// instruction i is a scalar base plus ONE xor on a per-lane constant, and the DPT docs of a tile finish together (quarter /
+// half exchanges instead of a per-doc reduction).  Same k-order, same sum tree: scores are bit-identical to the general
+// kernels'.  Padding slots (pid out of range) fetch row 0 and are overwritten with -inf at the end; no 0-floor exists in a
+// uniform index (its only length bucket is L itself, colbert_ranker.py:36-40,90).
+// (one 16-column query block needs <= 96 registers: five waves per SIMD -- with 4-wave workgroups of 32 KiB that is five
+//  workgroups = 20 streams per CU instead of 16; the second launch bound asks the compiler to stay there)
+template <int WAVES, int NCB, int L, int ABLATE = 0>
+__global__ void __launch_bounds__(WAVES * 64, NCB == 1 ? 5 : 3) k_maxsim_stream_uni(KARGS_DECL) {
+  static_assert(L == 4 || L == 8 || L == 16, "uniform doc length: 4, 8 or 16 tokens");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KARGS_TO_PARAMS;
+  constexpr int ROWB = 512, HT = 16 * ROWB, NDMA = 8, DPT = 16 / L;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  int qi, chunk;
+  wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
+  const int dpwv = p.dpw / WAVES;
+  const int c_begin = chunk * p.dpw + wave * dpwv;
+  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  if (ndoc == 0) return;
+  float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
+  // descriptor lanes: lane j = first token row of the wave's j-th doc
+  uint32_t row0 = 0;
+  bool bad = true;
+  if (lane < ndoc) {
+    const int64_t pid = p.cand[(int64_t)qi * p.ncand + c_begin + lane];
+    bool ok = pid >= 0 && pid < p.n_docs;
+    const DocMeta dm = load_doc_meta(p, ok ? pid : 0);
+    ok = ok && dm.len == L && dm.off >= 0 && dm.off + L <= p.n_tokens;
+    row0 = ok ? (uint32_t)dm.off : 0u;
+    bad = !ok;
+  }
+  char* const wlds = lds + wave * HT;
+  const int n16 = lane & 15, kq = lane >> 4;
+  const char* const tok = (const char*)p.index;
+  const int ntile = (ndoc + DPT - 1) / DPT;
+  // DMA instruction i moves tile rows 2 i (lanes 0..31) and 2 i + 1 (lanes 32..63); chunk position c of row s receives
+  // source chunk c ^ (s & 15): per lane  off_i = ds0 * 512 + 16 * ((dch ^ ds0) ^ (2 i & 15)) = lane_off ^ (32 i)
+  const uint32_t lane_off = (uint32_t)((lane >> 5) * ROWB + 16 * ((lane & 31) ^ (lane >> 5)));
+  auto issue = [&](int t) __attribute__((always_inline)) {
+    if (ABLATE == 2) return;
+    uint32_t base[DPT];
+#pragma unroll
+    for (int d = 0; d < DPT; ++d) base[d] = (uint32_t)__builtin_amdgcn_readlane((int)row0, min(t * DPT + d, ndoc - 1));
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const char* const g = tok + (uint64_t)(base[(2 * i) / L] + (uint32_t)((2 * i) % L)) * ROWB;
+      __builtin_amdgcn_global_load_lds(GPTR(g + (lane_off ^ (uint32_t)(32 * i))), LPTR(wlds + i * 1024), 16, 0, CPOL_STREAM);
+    }
+  };
+  issue(0);
+  // lane (n, kq) holds Q[16 cb + n][16 j + 4 kq + t] in qv[8 cb + j][t]
+  f32x4 qv[8 * NCB];
+  {
+    int qlen = p.Lq;
+    if (p.q_len) qlen = min(qlen, p.q_len[qi]);
+    const bool qf32 = p.q_dtype == MAXSIM_F32;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int qt = p.q_tok0 + 16 * cb + n16;
+      const bool live = q_token_live<MODE_RERANK>(p, qi, qt, qlen);
+      const int64_t qo = ((int64_t)qi * p.Lq + (live ? qt : 0)) * 128;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        f32x4 v;
+        if (qf32) {
+          v = *(const f32x4*)((const float*)p.Q + qo + 16 * j + 4 * kq);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, qo + 16 * j + 4 * kq + t);
+        }
+        qv[8 * cb + j] = live ? v : (f32x4)(0.0f);
+      }
+    }
+  }
+  float myscore = 0.0f;
+  for (int t = 0; t < ntile; ++t) {
+    __builtin_amdgcn_s_setprio(0);
+    wait_vmcnt<0>();
+    u32x4 a[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = *(const u32x4*)(wlds + n16 * ROWB + 16 * ((4 * j + kq) ^ n16));
+    wait_lgkmcnt0();
+    if (t + 1 < ntile) issue(t + 1);
+    __builtin_amdgcn_s_setprio(3);
+    f32x4 acc[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[cb] = (f32x4)(0.0f);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (ABLATE == 1) {
+        asm volatile("" ::"v"(a[j]));
+        continue;
+      }
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(__builtin_bit_cast(f32x4, a[j])[tt], qv[8 * cb + j][tt], acc[cb], 0, 0, 0);
+    }
+    // acc[cb][v] = similarity of query token 16 cb + n16 with tile row 4 kq + v; doc d of the tile = rows [d L, (d + 1) L)
+    float tree[NCB];
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      float m = fmaxf(fmaxf(acc[cb][0], acc[cb][1]), fmaxf(acc[cb][2], acc[cb][3]));  // the quarter's 4 rows
+      if constexpr (L >= 8) {  // quarters g, g + 1
+        const uint32_t xb = __float_as_uint(m);
+        const auto s16 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+        m = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+      }
+      if constexpr (L == 16) {  // quarters g, g + 2
+        const uint32_t xb = __float_as_uint(m);
+        const auto s32 = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+        m = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+      }
+      // sum over the block's 16 query-token lanes: the general kernels' pairwise tree
+      m += dpp_f32<0xB1>(m);
+      m += dpp_f32<0x4E>(m);
+      m += dpp_f32<0x141>(m);
+      m += dpp_f32<0x140>(m);
+      tree[cb] = m;
+    }
+#pragma unroll
+    for (int d = 0; d < DPT; ++d) {  // doc d's sums sit in the 16-lane row that holds its rows: lane d * (64 / DPT)
+      float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tree[0]), d * (64 / DPT)));
+      if constexpr (NCB == 2) sc += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tree[1]), d * (64 / DPT)));
+      myscore = (lane == t * DPT + d) ? sc : myscore;
+    }
+  }
+  if (lane < ndoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + (bad ? NEG_INF : myscore);
+}
+
 }  // namespace maxsim

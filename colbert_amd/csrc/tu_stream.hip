@@ -33,6 +33,32 @@ int launch_stream_f32h(Params& p, hipStream_t st) {
   return check_launch();
 }
 
+// every doc exactly L tokens (maxsim_index_view.uniform_len): the fixed-length kernel, one 8 KiB tile per wave
+template <int WAVES, int NCB, int L, int ABLATE = 0>
+int launch_stream_uni(Params& p, hipStream_t st) {
+  int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
+  p.dpw = dpwv * WAVES;
+  p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+  const int ldsb = WAVES * 8192;
+  auto kern = k_maxsim_stream_uni<WAVES, NCB, L, ABLATE>;
+  int rc = allow_lds(kern, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  return check_launch();
+}
+template <int L>
+int launch_stream_uni_l(Params& p, bool many, hipStream_t st) {
+#ifdef MAXSIM_DIAG
+  const int variant = MAXSIM_KNOB("MAXSIM_VARIANT", 0);
+  if (variant == 1) return launch_stream_uni<8, 1, L, 1>(p, st);  // no MFMA (timing only, wrong results)
+  if (variant == 2) return launch_stream_uni<8, 1, L, 2>(p, st);  // no DMA  (timing only, wrong results)
+#endif
+  const int waves = MAXSIM_KNOB("MAXSIM_UNI_WAVES", 0);  // (diagnostic: force 4- or 8-wave workgroups)
+  if (waves == 8 || (waves == 0 && many)) return p.Lq <= 16 ? launch_stream_uni<8, 1, L>(p, st) : launch_stream_uni<8, 2, L>(p, st);
+  return p.Lq <= 16 ? launch_stream_uni<4, 1, L>(p, st) : launch_stream_uni<4, 2, L>(p, st);
+}
+
 // Per-wave LDS ring: fp32 1 x 16 KiB tile, 16-bit 2 x 8 KiB tiles; 4 waves per workgroup = 64 KiB, two
 // workgroups per CU.  MAXSIM_VARIANT exists in diagnostic builds only (-DMAXSIM_DIAG; DESIGN.md "Tuning knobs"):
 // 1/2 = ablation kernels (timing only, WRONG scores) -- the shipped library does not even contain them.
@@ -50,7 +76,7 @@ int launch_stream(Params& p, hipStream_t st) {
     // short stream arrive sooner and tiles straddle fewer docs: +5-7 % at 8-16 tokens per doc, -2 % from 32 up.
     // (diagnostic: MAXSIM_VARIANT=6 forces this kernel, 8 disables it)
     const bool short_docs = p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs;
-    if (variant == 6 || (short_docs && variant == 0)) {
+    if (variant == 6 || (short_docs && (variant == 0 || variant == 1 || variant == 2))) {
       // Very short docs (<= 16 tokens on average; the 8-token multi-view config): ONE half tile per wave and twice the
       // waves -- 16 per CU -- instead of two tiles per wave and 8 waves.  These launches are bound by how many independent
       // doc streams are in flight, not by bytes in flight per stream: 256 queries x 1000 eight-token docs 0.200 -> 0.185 ms
@@ -60,6 +86,13 @@ int launch_stream(Params& p, hipStream_t st) {
       const int shape = MAXSIM_KNOB("MAXSIM_F32H_SHAPE", 0);
       const bool very_short = p.n_tokens <= 16 * p.n_docs;
       const bool many = (int64_t)p.nq * ((p.ncand + 511) / 512) >= 256;
+      // every doc the same 4 / 8 / 16 tokens (the multi-view configuration): the kernel with the length compiled in
+      // (diagnostic: MAXSIM_F32H_SHAPE != 0 keeps the general half-tile kernels)
+      if (shape == 0 && variant != 6 && p.n_tokens == (int64_t)p.uniform_len * p.n_docs) {
+        if (p.uniform_len == 8) return launch_stream_uni_l<8>(p, many, st);
+        if (p.uniform_len == 4) return launch_stream_uni_l<4>(p, many, st);
+        if (p.uniform_len == 16) return launch_stream_uni_l<16>(p, many, st);
+      }
       const int pick = shape ? shape : (!very_short ? 3 : many ? 2 : 1);
       if (pick == 2) return p.Lq <= 16 ? launch_stream_f32h<8, 1, 1>(p, st) : launch_stream_f32h<8, 2, 1>(p, st);
       if (pick == 1) return p.Lq <= 16 ? launch_stream_f32h<4, 1, 1>(p, st) : launch_stream_f32h<4, 2, 1>(p, st);

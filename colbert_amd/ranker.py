@@ -191,8 +191,12 @@ class ColbertRanker:
         idt = _DT[self.tensor.dtype]
         if idt == _lib.F32:
             idt = {"exact": _lib.F32, "fast": _lib.F32_FAST, "bf16x3": _lib.F32_BF16X3}[getattr(self, "fp32_mode", "exact")]
+        # every doc the same length and that length the only bucket (no padding anywhere): the multi-view configuration
+        # (dense.yaml:31-32: every doc keeps d_view viewer tokens) -- the library then runs its fixed-length kernel
+        lo, hi = int(self.doclens.min().item()), int(self.doclens.max().item())
+        uniform = lo if (lo == hi and lo > 0 and lo in self.strides) else 0    # lo in strides: pad_len == doclen
         return _lib.IndexView(_ptr(self.tensor), idt, self.dim, self.num_embeddings, _ptr(self.d_offsets),
-                              _ptr(self.d_doclens), _ptr(self.d_pad_len), self.n_docs, _ptr(self.d_doc_table))
+                              _ptr(self.d_doclens), _ptr(self.d_pad_len), self.n_docs, _ptr(self.d_doc_table), uniform, 0)
 
     # ------------------------------------------------------------------------------------------
     def score_candidates(self, Q, cand_pids, q_len=None, q_mask=None, cand_count=None):

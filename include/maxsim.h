@@ -42,9 +42,10 @@
 extern "C" {
 #endif
 
-#define MAXSIM_VERSION 120 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
+#define MAXSIM_VERSION 121 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
                               maxsim_shard_candidates, maxsim_build_doc_table; 111: maxsim_score_dense_kernel;
-                              120: counted candidate rows (maxsim_rerank_counted, maxsim_topk_counted) */
+                              120: counted candidate rows (maxsim_rerank_counted, maxsim_topk_counted);
+                              121: maxsim_index_view.uniform_len, read-ceiling probes, maxsim_host_alloc_coherent */
 
 /* element types of Q / D / index */
 #define MAXSIM_F32 0
@@ -195,6 +196,13 @@ typedef struct maxsim_index_view {
   int64_t n_docs;
   const void* doc_table;      /* NULL, or n_docs packed 16-byte rows written by maxsim_build_doc_table from the three
                                  arrays above: the kernels then read one cache line per candidate instead of three */
+  int32_t uniform_len;        /* 0, or L > 0: EVERY doc has exactly L tokens and no doc is padded (pad_len NULL or == L
+                                 everywhere) -- the reference's multi-view configuration, where every doc keeps d_view
+                                 viewer tokens (proj_conf/dense.yaml:31-32).  A promise by the caller, who knows the
+                                 doclens on the host; for h == 128, an fp32 index and L in {4, 8, 16} the rerank then
+                                 runs a kernel with the doc length compiled in (bit-identical scores, ~15 % faster).
+                                 A doc whose table length differs from L is scored -inf. */
+  int32_t reserved;           /* 0 */
 } maxsim_index_view;
 
 /* Bytes of the packed descriptor table of n_docs docs (16 per doc). */
@@ -297,6 +305,11 @@ void maxsim_host_free(void* p);
  * kernel's ring), 1 = two 8 KiB tiles (the 16-bit kernels' ring), 2 = two 16 KiB tiles.  buf must be 16-byte aligned.
  */
 int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* bytes_read, void* stream);
+/* The same rings fed with SCATTERED pieces: `read_bytes` (a multiple of 1 MiB) are read as granules of `granule` bytes (a
+ * power of two, 1 KiB .. 1 MiB: one short doc) taken from hashed positions of the first `bytes` of buf -- the ceiling of
+ * a rerank over short docs (C4: 4 KiB docs).  variant: 0 = one 16 KiB tile per wave, 1 = two 8 KiB tiles, 2 = one 8 KiB
+ * tile per wave (the short-doc kernel: 16 waves per CU), 3 = the same with twice the bytes per wave. */
+int maxsim_hbm_read_probe_scattered(const void* buf, int64_t bytes, int granule, int variant, int64_t read_bytes, void* stream);
 
 #ifdef __cplusplus
 }

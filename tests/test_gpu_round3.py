@@ -296,3 +296,61 @@ def test_rank_forward_concurrent_threads_and_streams(ca):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert not errors, errors[:5]
+
+
+# ------------------------------------------------------------------------------------------------------
+# uniform short docs (the multi-view configuration, BASELINE configs[3]): the fixed-length kernel
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("L", [4, 8, 16])
+@pytest.mark.parametrize("Lq", [8, 16, 27, 40])
+def test_uniform_short_docs_kernel_is_bit_identical(ca, L, Lq):
+    """An index whose every doc has exactly L tokens runs k_maxsim_stream_uni (doc length compiled in); its scores equal,
+    bit for bit, those of the general half-tile kernel on the same index (the same ranker with the promise withdrawn:
+    uniform_len = 0) and agree with the oracle's closed form; padding slots, out-of-range pids, row widths that leave the
+    last tile / wave / workgroup partly filled, q_mask, queries longer than 32 tokens (accumulating passes)."""
+    import copy
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(100 + L)
+    ndocs, h = 5000, 128
+    doclens = [L] * ndocs
+    emb = nrm(gen, sum(doclens), h)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=torch.float32)
+    assert r._iv.uniform_len == L
+    g = copy.copy(r)                                     # the same index without the promise -> general kernels
+    g._iv = r._index_view()
+    g._iv.uniform_len = 0
+    g._iv_ref = ctypes.byref(g._iv)
+    for nq, ncand in ((1, 1), (3, 7), (2, 65), (5, 1000), (300, 130), (2, 2049)):
+        Q = nrm(gen, nq, Lq, h)
+        cand = torch.randint(0, ndocs, (nq, ncand), generator=gen)
+        if ncand > 3:
+            cand[0, 1] = -1                              # padding slot
+            cand[-1, ncand - 2] = ndocs + 3              # out of range
+        qm = (torch.rand(nq, Lq, generator=gen) > 0.25).long()
+        qm[:, 0] = 1
+        for kw in (dict(), dict(q_mask=qm)):
+            a = r.score_candidates(Q, cand.cuda(), **kw).cpu()
+            b = g.score_candidates(Q, cand.cuda(), **kw).cpu()
+            assert torch.equal(a, b), (L, Lq, nq, ncand, list(kw))
+        if ncand > 3:
+            assert float(a[0, 1]) == float("-inf") and float(a[-1, ncand - 2]) == float("-inf")
+        if nq <= 5 and ncand <= 1000:
+            for qi in range(nq):
+                ok = [(c, p) for c, p in enumerate(cand[qi].tolist()) if 0 <= p < ndocs][:40]
+                exp = ragged_scores_f64(emb, r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi][qm[qi].bool()], [p for _, p in ok])
+                np.testing.assert_allclose(a[qi, [c for c, _ in ok]].numpy(), exp, rtol=0, atol=ATOL32)
+
+
+def test_uniform_promise_only_for_uniform_unpadded_indexes(ca):
+    """ColbertRanker sets uniform_len only when every doc has the same length AND that length is the only length bucket
+    (no doc padded): a shard re-bucketed by the strides of a ragged whole index does not qualify."""
+    gen = torch.Generator().manual_seed(2)
+    emb = nrm(gen, 8 * 50, 128)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[[8] * 50], dim=128, index_dtype=torch.float32)
+    assert r._iv.uniform_len == 8
+    r.set_strides([8, 20])                               # global strides of a whole index with longer docs elsewhere
+    assert r._iv.uniform_len == 8                        # still unpadded: 8 is a bucket of its own
+    r.set_strides([12, 20])                              # every doc now sits in the 12-bucket: padded, 0-floor applies
+    assert r._iv.uniform_len == 0
+    rag = ca.ColbertRanker(parts=[emb], parts_doclens=[[8] * 49 + [4, 4]], dim=128, index_dtype=torch.float32)
+    assert rag._iv.uniform_len == 0
