@@ -1,10 +1,10 @@
 #!/bin/bash
 # On the GPU box: rocprofv3 kernel-trace + PMC passes of bench.py for the round's profiled workloads.
-# usage: tools/run_profiles.sh <round-tag, e.g. r02> "<names>"      names from: c2_f32 c2_fp16 c2_f32fast c2_f32bf16x3 c5_bf16
-#        c4_f32 ragged_f32 shard8_f32 (one rank's share of an 8-way doc-sharded job) single_query
+# usage: tools/run_profiles.sh <round-tag, e.g. r03> "<names>"      names from: c2_f32 c2_fp16 c2_f32fast c2_f32bf16x3 c5_bf16
+#        c4_f32 ragged_f32 dep768_fp16 c2_shard8_f32 (one rank's share of an 8-way doc-sharded job) single_query
 set -u
-TAG=${1:-r02}
-NAMES=${2:-"c2_f32 c2_fp16 c2_f32fast c2_f32bf16x3 c5_bf16 c4_f32 ragged_f32 shard8_f32 single_query"}
+TAG=${1:-r03}
+NAMES=${2:-"c2_f32 c2_fp16 c2_f32bf16x3 c5_bf16 c4_f32 ragged_f32 dep768_fp16 c2_shard8_f32 single_query"}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 prof() {  # name, bench args...
@@ -24,7 +24,8 @@ for n in $NAMES; do
     c5_bf16) prof c5_bf16 --workload c5 ;;
     c4_f32) prof c4_f32 --workload c4 ;;
     ragged_f32) prof ragged_f32 --workload ragged ;;
-    shard8_f32) prof shard8_f32 --workload c2 --as-rank 3 --of 8 ;;
+    dep768_fp16) prof dep768_fp16 --workload dep768 ;;
+    c2_shard8_f32) prof c2_shard8_f32 --workload c2 --as-rank 3 --of 8 ;;
     single_query)  # the reference's online call: one rank_forward per query (tools/bench_small.py loops it)
       NDOCS=1000000 NQS=1,16 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_single_query_trace -- python3 $R/tools/bench_small.py > $R/gpurun_out/${TAG}_single_query_trace.log 2>&1 &&
       NDOCS=1000000 NQS=1,16 DTYPE=fp16 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_single_query_fp16_trace -- python3 $R/tools/bench_small.py > $R/gpurun_out/${TAG}_single_query_fp16_trace.log 2>&1 && echo "profiled single_query" ;;
