@@ -273,7 +273,7 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
     p.worklist = worklist;
     const int D0 = stream_list_docs_per_item(p);
     int32_t* const wl = (int32_t*)worklist;
-    hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, LIST_MIN_ITEMS, wl);
+    hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, wl);
     hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
     if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
     const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * LIST_MIN_ITEMS + nq;
@@ -290,6 +290,23 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
   const int esz = (index_dtype == MAXSIM_F32 || index_dtype >= MAXSIM_F32_FAST) ? 4 : 2;
   if (h >= 16 && h <= 1024 && ((h * esz) & 15) == 0 && stream_ok) {
     const int dt = index_dtype >= MAXSIM_F32_FAST ? MAXSIM_F32 : index_dtype;
+    // counted rows on wide embeddings (the reference's default dim 768): workgroup items -- the waves of a workgroup share
+    // the staged query image -- of waves x (a ~1.4 k-token stream per wave) docs
+    const int lw = (cand_count && worklist && ((uintptr_t)worklist & 15) == 0 && worklist_bytes >= maxsim_worklist_bytes(nq, ncand) &&
+                    ncand < (1 << WL_SLOT_BITS)) ? bigh_list_waves(p, dt) : 0;
+    if (lw > 0) {
+      p.worklist = worklist;
+      const int D0 = stream_list_docs_per_item(p) * lw;
+      int32_t* const wl = (int32_t*)worklist;
+      hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64 * lw, 256, wl);
+      hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
+      if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
+      const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * 256 + nq;
+      const int64_t max_items = by_rows > small ? by_rows : small;
+      int rc = for_query_slices(p, [&] { return launch_bigh_rerank_list(p, dt, max_items, st); });
+      if (rc != MAXSIM_ERANGE) return rc;
+      p.worklist = nullptr;  // (not reached: bigh_list_waves said the form serves this launch)
+    }
     int rc = for_query_slices(p, [&] { return launch_bigh_rerank(p, dt, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }

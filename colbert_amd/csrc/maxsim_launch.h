@@ -94,6 +94,10 @@ int launch_stream_small(Params& p, int index_dtype, hipStream_t st);
 // Return MAXSIM_ERANGE when the query image does not fit in LDS.
 int launch_bigh_rerank(Params& p, int dt, hipStream_t st);
 int launch_bigh_dense(Params& p, int dt, bool argmax, hipStream_t st);
+// tu_bigh_rerank_list.hip: the same kernel walking a work list of WORKGROUP items (counted rows; maxsim_worklist.h).
+// bigh_list_waves: waves per workgroup of that form for this launch, 0 = not served.
+int bigh_list_waves(const Params& p, int dt);
+int launch_bigh_rerank_list(Params& p, int dt, int64_t max_items, hipStream_t st);
 // tu_allpairs.hip: the GEMM-blocked all-pairs kernel (16-bit operands, Lq <= 32, Ld <= 384); MAXSIM_ERANGE = not its shape.
 int launch_allpairs(const Params& p, int dt, bool argmax, hipStream_t st);
 bool allpairs_serves(int dt, int q_dtype, int mask_dtype, int nq, int nd, int Lq, int Ld, int h);

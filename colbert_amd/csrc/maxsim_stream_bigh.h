@@ -132,8 +132,11 @@ struct MultiReducer {
 
 // PART: h is not a multiple of 128 (but of 16 bytes): the last block is partial -- the query image is zero past h and
 // the doc fetch never leaves the row (issue_rows<PART>).
-template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false>
+// LIST (counted candidate rows, maxsim_worklist.h): a fixed grid whose WORKGROUPS walk the device-built list of workgroup
+//   items (query, first slot, docs); an item's docs are dealt evenly over the waves, the query image is staged per item.
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
+  static_assert(!LIST || (MODE == MODE_RERANK && QB == 1 && !AM), "work-list form: rerank, one query per workgroup");
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
   static_assert(!AM || MODE == MODE_DENSE, "arg-max tracking is a dense (training-form) feature");
   static_assert(QB == 1 || MODE == MODE_DENSE, "several queries share documents only in the all-pairs form");
@@ -148,17 +151,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   const uint32_t rowbytes = (uint32_t)p.h * ESZ;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  int qblk, chunk;
-  if constexpr (MODE == MODE_RERANK) {
-    wg_to_work((int)blockIdx.x, (p.nq + QB - 1) / QB, p.nchunk, qblk, chunk);
-  } else {  // all-pairs: query-block-major (a doc chunk's query blocks close in time re-read it from cache)
-    qblk = blockIdx.x / p.nchunk;
-    chunk = blockIdx.x - qblk * p.nchunk;
-  }
-  const int q0 = qblk * QB;  // first query of this workgroup; queries past nq - 1 are clamped and not written
-  const int dpwv = p.dpw / WAVES;
-  const int c_begin = chunk * p.dpw + wave * dpwv;
-  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  // one workgroup item: the wave's candidates [c_begin, c_begin + ndoc) of the queries q0 .. q0 + QB - 1
+  auto wg_item = [&](const int q0, const int c_begin, const int ndoc) __attribute__((always_inline)) {
   const DocLanes dl = load_doc_lanes<MODE>(p, q0, c_begin, ndoc, lane);
   const int qimg = NPQ * KB * SUB;                          // one query's image: [NPQ][KB][32 rows][BLKB]
   char* const qlds = lds;
@@ -357,6 +351,36 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       float* const cell = p.scores + (int64_t)(q0 + x) * p.ncand + c_begin + lane;
       *cell = (p.accum ? *cell : 0.0f) + red.myscore[x];
     }
+  };  // wg_item
+  if constexpr (LIST) {
+    // workgroup slot s = blockIdx.x, + gridDim.x, ... (the grid is a multiple of 8); slot -> item is XCD-aware as in the
+    // h = 128 list kernel: the slots with s % 8 = x walk the x-th eighth of the list in order
+    const int32_t* const wl = (const int32_t*)p.worklist;
+    const int J = uni(wl[0]), Jx = (J + 7) >> 3;
+    const int2* const wl_items = (const int2*)(wl + worklist_items_word(p.nq));
+    for (int s = (int)blockIdx.x; s < 8 * Jx; s += (int)gridDim.x) {
+      const int item = (s & 7) * Jx + (s >> 3);
+      if ((s >> 3) >= Jx || item >= J) continue;
+      const int2 e = wl_items[item];
+      const int first = uni(e.y) & ((1 << WL_SLOT_BITS) - 1), n = uni(e.y) >> WL_SLOT_BITS;
+      const int b0 = (int)((int64_t)wave * n / WAVES), b1 = (int)((int64_t)(wave + 1) * n / WAVES);
+      __builtin_amdgcn_s_setprio(0);
+      wg_item(uni(e.x), first + b0, b1 - b0);
+      __syncthreads();  // every wave is done with this item's query image: the next item may stage its own
+    }
+  } else {
+    int qblk, chunk;
+    if constexpr (MODE == MODE_RERANK) {
+      wg_to_work((int)blockIdx.x, (p.nq + QB - 1) / QB, p.nchunk, qblk, chunk);
+    } else {  // all-pairs: query-block-major (a doc chunk's query blocks close in time re-read it from cache)
+      qblk = blockIdx.x / p.nchunk;
+      chunk = blockIdx.x - qblk * p.nchunk;
+    }
+    const int dpwv = p.dpw / WAVES;
+    const int c_begin = chunk * p.dpw + wave * dpwv;
+    // (queries past nq - 1 are clamped and not written)
+    wg_item(qblk * QB, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
+  }
 }
 
 }  // namespace maxsim

@@ -13,14 +13,17 @@
 // Layout of the work list (device memory, int32 words):
 //   [0] number of wave items   [1] docs per item the builder settled on   [2] live candidates in all rows   [3..15] 0
 //   [16 .. 16 + nq]            item_start[q] (exclusive prefix sum of the rows' item counts; [nq] = word 0)
-//   then, 16-byte aligned:     items[] as int2 {query, first slot | docs << 24}
+//   then, 16-byte aligned:     items[] as int2 {query, first slot | docs << 20}
+// The h = 128 kernels take WAVE items (<= 64 docs, a wave's stream); the LDS-query kernel for wider rows, whose waves share
+// the staged query, takes WORKGROUP items (<= 64 docs per wave: docs per item = waves x docs per wave) and deals an item's
+// docs evenly over its waves.
 #pragma once
 #include "maxsim_common.h"
 
 namespace maxsim {
 
 constexpr int WL_HEADER_WORDS = 16;
-constexpr int WL_SLOT_BITS = 24;  // first slot < 2^24; docs per item <= 64
+constexpr int WL_SLOT_BITS = 20;  // first slot < 2^20; docs per item < 2^11
 __host__ __device__ inline int64_t worklist_items_word(int nq) { return (WL_HEADER_WORDS + (int64_t)nq + 1 + 3) & ~(int64_t)3; }
 
 __device__ __forceinline__ int wl_row_count(const int32_t* __restrict__ counts, int q, int ncand) {
@@ -31,7 +34,7 @@ __device__ __forceinline__ int wl_row_count(const int32_t* __restrict__ counts, 
 // halved while the launch would have fewer than `min_items` items: a small launch is better off with more, shorter
 // streams -- the rule pick_docs_per_wave applies on the host to static grids); (2) exclusive scan of ceil(count / D).
 static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __restrict__ counts, int nq, int ncand, int D0,
-                                                        int min_items, int32_t* __restrict__ wl) {
+                                                        int Dmax, int min_items, int32_t* __restrict__ wl) {
   __shared__ long long red[16];
   __shared__ int wsum[16];
   __shared__ int carry_s, D_s;
@@ -44,7 +47,7 @@ static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __
   if (tid == 0) {
     long long t = 0;
     for (int w = 0; w < 16; ++w) t += red[w];
-    int D = D0 < 1 ? 1 : (D0 > 64 ? 64 : D0);
+    int D = D0 < 1 ? 1 : (D0 > Dmax ? Dmax : D0);
     while (D > 1 && (t + D - 1) / D < min_items) D = (D + 1) / 2;
     D_s = D;
     carry_s = 0;

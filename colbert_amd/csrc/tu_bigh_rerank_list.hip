@@ -1,0 +1,71 @@
+// tu_bigh_rerank_list.hip -- the LDS-query streaming kernel (maxsim_stream_bigh.h) walking a device-built work list of
+// WORKGROUP items: counted candidate rows (a doc shard's share of every list, ANN pid lists) for rows wider than 128
+// dims -- the reference's default deployment is dim 768 (proj_conf/dense.yaml:8).
+#include "maxsim_launch_bigh.h"
+
+namespace maxsim {
+namespace {
+
+// The ring shape launch_stream_bigh_q would pick for a rerank launch of this width / type (waves, sub-tiles per wave).
+template <int DT, int NPQ>
+bool list_shape(const Params& p, int& waves, int& nt) {
+  constexpr int SUB = StreamTraits<DT>::TILE;
+  const int avail = 160 * 1024 - NPQ * ((p.h + 127) / 128) * SUB;
+  if (avail >= 8 * 2 * SUB) { waves = 8; nt = 2; return true; }
+  if (NPQ == 2 && avail >= 8 * 1 * SUB) { waves = 8; nt = 1; return true; }
+  if (avail >= 4 * 2 * SUB) { waves = 4; nt = 2; return true; }
+  if (avail >= 4 * 1 * SUB) { waves = 4; nt = 1; return true; }
+  return false;
+}
+
+template <int DT, int NPQ>
+int launch_list(Params& p, int64_t max_items, hipStream_t st) {
+  constexpr int SUB = StreamTraits<DT>::TILE;
+  int waves = 0, nt = 0;
+  if (!list_shape<DT, NPQ>(p, waves, nt)) return MAXSIM_ERANGE;
+  const int KB = (p.h + 127) / 128;
+  const int ldsb = NPQ * KB * SUB + waves * nt * SUB;
+  // one workgroup per CU is resident (the query image + rings take most of the LDS): a few rounds of them
+  int64_t wgs = max_items < 1 ? 1 : max_items;
+  const int cap = MAXSIM_KNOB("MAXSIM_LIST_WGS", 1024);
+  if (wgs > cap) wgs = cap;
+  wgs = (wgs + 7) & ~(int64_t)7;
+  auto go = [&](auto kern) {
+    int rc = allow_lds(kern, ldsb);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
+    return check_launch();
+  };
+  if (waves == 8 && nt == 2) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 8, 2, false, 1, false, true>);
+  if (waves == 8) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 8, 1, false, 1, false, true>);
+  if (nt == 2) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 4, 2, false, 1, false, true>);
+  return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 4, 1, false, 1, false, true>);
+}
+
+}  // namespace
+
+// Waves per workgroup of the list form for this launch (0: not served -- widths that are not a multiple of 128, or a
+// query image that does not fit), so that the caller can size the workgroup items (docs per item = waves x docs per wave).
+int bigh_list_waves(const Params& p, int dt) {
+  if (p.h & 127) return 0;
+  const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;
+  int waves = 0, nt = 0;
+  bool ok;
+  switch (dt) {
+    case MAXSIM_F32: ok = list_shape<MAXSIM_F32, 1>(p, waves, nt); break;
+    case MAXSIM_F16: ok = same16 ? list_shape<MAXSIM_F16, 1>(p, waves, nt) : list_shape<MAXSIM_F16, 2>(p, waves, nt); break;
+    default: ok = same16 ? list_shape<MAXSIM_BF16, 1>(p, waves, nt) : list_shape<MAXSIM_BF16, 2>(p, waves, nt); break;
+  }
+  return ok ? waves : 0;
+}
+
+int launch_bigh_rerank_list(Params& p, int dt, int64_t max_items, hipStream_t st) {
+  const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;
+  switch (dt) {
+    case MAXSIM_F32: return launch_list<MAXSIM_F32, 1>(p, max_items, st);
+    case MAXSIM_F16: return same16 ? launch_list<MAXSIM_F16, 1>(p, max_items, st) : launch_list<MAXSIM_F16, 2>(p, max_items, st);
+    default: return same16 ? launch_list<MAXSIM_BF16, 1>(p, max_items, st) : launch_list<MAXSIM_BF16, 2>(p, max_items, st);
+  }
+}
+
+}  // namespace maxsim

@@ -6,8 +6,8 @@ Per query the reference does: ``keep_nonzero`` (drop the tokens ``q_active_paddi
 sit MID-sequence, colbert/modeling/tokenizers.py:36) -> ANN search of the live tokens -> embedding ids -> distinct pids
 (``emb2pid`` + ``set()``, colbert/ranking/colbert_ranker.py:176-229) -> ``rank_forward`` -> ``(pids, scores)``.
 Here every step after the ANN search is one launch for the batch: ids -> distinct pids (``maxsim_embedding_ids_to_pids``),
-fused rerank with the keep-mask as a per-token predicate (``maxsim_rerank_ex``; nothing is compacted), top-k, and ONE
-device->host copy.  The ANN search itself is third-party (FAISS) and stays outside: pass its result, or a callable.
+fused rerank of the counted rows with the keep-mask as a per-token predicate (``maxsim_rerank_counted``; nothing is
+compacted, nothing read back), counted top-k, and ONE device->host copy.  The ANN search itself is third-party (FAISS) and stays outside: pass its result, or a callable.
 """
 import torch
 
@@ -39,9 +39,12 @@ def retrieve_batch(ranker, Q, q_active_padding, topk, embedding_ids=None, ann_se
         embedding_ids = embedding_ids.to(device=dev, dtype=torch.int64)
         assert embedding_ids.dim() == 3 and tuple(embedding_ids.shape[:2]) == (bs, Lq)
         embedding_ids = torch.where(keep.unsqueeze(-1), embedding_ids, torch.full_like(embedding_ids, -1))
-    cand, counts = ranker.embedding_ids_to_pids(embedding_ids.reshape(bs, -1))       # colbert_ranker.py:178, :212-229
+    # distinct pids per query as COUNTED rows (live pids first, -1 behind): the rerank builds its launch from the counts
+    # on the device (maxsim_rerank_counted), so the row width is never read back to trim it -- no host sync before the
+    # one copy of the results
+    cand, counts = ranker.embedding_ids_to_pids(embedding_ids.reshape(bs, -1), trim=False)   # colbert_ranker.py:178, :212-229
     k = min(int(topk), cand.size(1))
-    top_p, top_s = ranker.rerank_batch(Q, cand, depth=k, q_mask=keep)                 # :75-137 for every query
+    top_p, top_s = ranker.rerank_batch(Q, cand, depth=k, q_mask=keep, cand_count=counts)      # :75-137 for every query
     host_p, host_s, host_n = top_p.cpu(), top_s.cpu(), counts.cpu()
     out = []
     for i in range(bs):

@@ -277,7 +277,7 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
  *   synchronisation to size the launch, no all-padding workgroups, every wave of every workgroup busy.  One rank's share
  *   of an 8-way sharded step then costs what the same docs cost as dense rows.  Other shapes take maxsim_rerank_ex's path.
  *   worklist: 16-byte aligned device scratch of maxsim_worklist_bytes(nq, ncand) bytes (contents need not survive the
- *   call; NULL or too small = maxsim_rerank_ex's path).  ncand < 2^24 for the list form.
+ *   call; NULL or too small = maxsim_rerank_ex's path).  ncand < 2^20 for the list form.
  * maxsim_topk_counted: maxsim_topk that ranks the live slots only (ncand <= 2048; longer rows ignore the counts).
  */
 int64_t maxsim_worklist_bytes(int nq, int ncand);

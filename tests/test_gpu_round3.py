@@ -74,6 +74,36 @@ def test_counted_rows_equal_full_width_rows(ca, cfg):
         assert torch.equal(s0.cpu(), s1.cpu()) and torch.equal(p0.cpu(), p1.cpu())
 
 
+@pytest.mark.parametrize("dtype,qdtype,h,Lq", [(torch.float16, torch.float32, 768, 32), (torch.float16, torch.float16, 768, 32),
+                                               (torch.bfloat16, torch.float32, 256, 20), (torch.float32, torch.float32, 384, 32),
+                                               (torch.float16, torch.float32, 768, 45), (torch.float16, torch.float32, 200, 32)])
+def test_counted_rows_on_wide_embeddings(ca, dtype, qdtype, h, Lq):
+    """Counted rows on rows wider than 128 dims (the reference's default deployment is dim 768): the LDS-query kernel walks a
+    work list of WORKGROUP items; bit-identical to the static grid.  (h = 200 is not a multiple of 128: static fallback.)"""
+    gen = torch.Generator().manual_seed(77)
+    ndocs, nq, ncand = 300, 23, 180
+    doclens = (torch.randn(ndocs, generator=gen) * 60 + 150).round().clamp(1, 384).long().tolist()
+    emb = nrm(gen, sum(doclens), h).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=dtype)
+    counts = torch.randint(0, ncand + 1, (nq,), generator=gen)
+    counts[0], counts[1], counts[2] = 0, ncand, 1
+    cand = _counted_rows(gen, nq, ncand, ndocs, counts)
+    cand[1, 7] = ndocs + 1
+    Q = nrm(gen, nq, Lq, h).to(qdtype)
+    qm = (torch.rand(nq, Lq, generator=gen) > 0.2).long()
+    qm[:, 0] = 1
+    for kw in (dict(), dict(q_mask=qm)):
+        full = r.score_candidates(Q, cand.cuda(), **kw)
+        cnt = r.score_candidates(Q, cand.cuda(), cand_count=counts.cuda(), **kw)
+        assert torch.equal(full.cpu(), cnt.cpu())
+    # a big, few-candidates-per-row launch (one rank's share of an 8-way step) and a tiny one
+    for nq2, ncand2, mean in ((200, 1000, 125), (2, 40, 9)):
+        c2 = torch.randint(max(0, mean - mean // 4), mean + mean // 4 + 1, (nq2,), generator=gen)
+        cd = _counted_rows(gen, nq2, ncand2, ndocs, c2)
+        Q2 = nrm(gen, nq2, Lq, h).to(qdtype)
+        assert torch.equal(r.score_candidates(Q2, cd.cuda()).cpu(), r.score_candidates(Q2, cd.cuda(), cand_count=c2.cuda()).cpu())
+
+
 def test_counted_rows_small_and_large_launches(ca):
     """The builder picks the docs per wave item ON THE DEVICE from the number of live candidates: a launch with few of
     them gets shorter items (more waves), one with many the ~1.4 k-token streams.  Both ends against the static grid."""
@@ -123,7 +153,7 @@ def test_worklist_layout(ca):
         assert len(mine) == (c + D - 1) // D
         pos = 0
         for qq, packed in mine.tolist():
-            b, n = packed & 0xffffff, packed >> 24
+            b, n = packed & 0xfffff, packed >> 20
             assert qq == q and b == pos and 1 <= n <= D
             pos += n
         assert pos == c
