@@ -282,7 +282,8 @@ def roofline_entry(kern_ms, alg_bytes, cand_tokens, lq, h, workload, index_dtype
             "mfma_tflops": round(2.0 * lq * h * cand_tokens / (kern_ms * 1e-3) / 1e12, 1)}
 
 
-def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32_mode="exact", reuse=None, label=None):
+def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32_mode="exact", reuse=None, label=None,
+                   online_call=False):
     """One more BASELINE / deployment workload on this GPU, 256 queries x 1000 candidates per step, the index built once
     (or `reuse` = (idx, doclens) of a workload that is still resident).  Not `value`: a labelled entry of other_workloads."""
     wl = WORKLOADS[name]
@@ -311,6 +312,8 @@ def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32
            "steps": steps, "warmup": warmup, "queries_per_s": round(NQ * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4)}
     out.update({k: rf[k] for k in ("kernel", "kernel_ms", "algorithmic_bytes_per_launch", "achieved", "frac", "traffic",
                                    "pmc_source", "mfma_busy_frac", "mfma_tflops")})
+    if online_call:     # the reference's online call on this index (its storage dtype): one rank_forward per query
+        out["single_query"] = single_query_probe(ranker, Q, cands, h, lq, esize)
     return out, (idx, doclens)
 
 
@@ -579,7 +582,7 @@ def main():
             # the closures above share these cells)
             ranker = sharded = idx = cands = score_inner = keep = None
             torch.cuda.empty_cache()
-            for name, kw, label in (("c2", dict(index_dtype="fp16"), "c2 with the reference's fp16 index (colbert_ranker.py:62)"),
+            for name, kw, label in (("c2", dict(index_dtype="fp16", online_call=True), "c2 with the reference's fp16 index (colbert_ranker.py:62)"),
                                     ("ragged", {}, "ragged fp32 (doclens N(120,40) in 8..180)"),
                                     ("c4", {}, "C4 multi-view: 8 x 8 tokens (BASELINE configs[3])"),
                                     ("c5", {}, "C5 bf16 dim 768, 32 x 256 tokens (BASELINE configs[4])"),
