@@ -174,6 +174,29 @@ int main(void) {
     hipMemcpy(&cnt, dcnt, 4, hipMemcpyDeviceToHost);
     CHECK(rc == MAXSIM_OK && cnt == 4 && loc[0] == 2 && loc[1] == 0 && loc[2] == 1 && loc[3] == 0 && loc[4] == -1 && loc[5] == -1 &&
               gl[0] == 12 && gl[1] == 10 && gl[2] == 11 && gl[3] == 10 && gl[4] == -1, "shard_candidates: stable in-range compaction");
+
+    /* counted rows: the compacted row (local pids 2 0 1 0, then -1 -1) with its device-side count through
+       maxsim_rerank_counted + maxsim_topk_counted == maxsim_rerank_ex + maxsim_topk on the same row */
+    const int64_t wlb = maxsim_worklist_bytes(1, 6);
+    void* dwl = NULL;
+    float *ds6 = NULL, *ds6c = NULL, *dts3 = NULL, *dtsc = NULL;
+    int64_t *dtp3 = NULL, *dtpc = NULL;
+    hipMalloc(&dwl, (size_t)wlb);
+    hipMalloc((void**)&ds6, 24); hipMalloc((void**)&ds6c, 24); hipMalloc((void**)&dts3, 12); hipMalloc((void**)&dtsc, 12);
+    hipMalloc((void**)&dtp3, 24); hipMalloc((void**)&dtpc, 24);
+    rc = maxsim_rerank_ex(&iv, dQ, MAXSIM_F32, NULL, NULL, dl, 1, 6, LQ, ds6, NULL);
+    int rc2 = maxsim_rerank_counted(&iv, dQ, MAXSIM_F32, NULL, NULL, dl, dcnt, 1, 6, LQ, ds6c, dwl, wlb, NULL);
+    int rc3 = maxsim_topk(ds6, dgo, 1, 6, 3, dts3, dtp3, NULL);
+    int rc4 = maxsim_topk_counted(ds6c, dgo, dcnt, 1, 6, 3, dtsc, dtpc, NULL);
+    float s6[6], s6c[6], ts3[3], ts3c[3];
+    int64_t tp3[3], tp3c[3];
+    hipDeviceSynchronize();
+    hipMemcpy(s6, ds6, 24, hipMemcpyDeviceToHost); hipMemcpy(s6c, ds6c, 24, hipMemcpyDeviceToHost);
+    hipMemcpy(ts3, dts3, 12, hipMemcpyDeviceToHost); hipMemcpy(ts3c, dtsc, 12, hipMemcpyDeviceToHost);
+    hipMemcpy(tp3, dtp3, 24, hipMemcpyDeviceToHost); hipMemcpy(tp3c, dtpc, 24, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && rc2 == MAXSIM_OK && rc3 == MAXSIM_OK && rc4 == MAXSIM_OK && wlb > 0, "counted rows: return codes");
+    CHECK(memcmp(s6, s6c, 24) == 0 && isinf(s6c[4]) && isinf(s6c[5]) && s6c[0] == 1.5f, "rerank_counted == rerank_ex (incl. the -inf tail)");
+    CHECK(memcmp(ts3, ts3c, 12) == 0 && memcmp(tp3, tp3c, 24) == 0 && tp3c[0] == 12, "topk_counted == topk");
   }
   printf("%s\n", failures ? "FAILED" : "ALL OK");
   return failures ? 1 : 0;
