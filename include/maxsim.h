@@ -196,12 +196,13 @@ typedef struct maxsim_index_view {
   int64_t n_docs;
   const void* doc_table;      /* NULL, or n_docs packed 16-byte rows written by maxsim_build_doc_table from the three
                                  arrays above: the kernels then read one cache line per candidate instead of three */
-  int32_t uniform_len;        /* 0, or L > 0: EVERY doc has exactly L tokens and no doc is padded (pad_len NULL or == L
-                                 everywhere) -- the reference's multi-view configuration, where every doc keeps d_view
-                                 viewer tokens (proj_conf/dense.yaml:31-32).  A promise by the caller, who knows the
-                                 doclens on the host; for h == 128, an fp32 index and L in {4, 8, 16} the rerank then
-                                 runs a kernel with the doc length compiled in (bit-identical scores, ~15 % faster).
-                                 A doc whose table length differs from L is scored -inf. */
+  int32_t uniform_len;        /* 0, or L > 0: EVERY doc has exactly L tokens (doclens[pid] == L, tok_offsets[pid] == pid * L:
+                                 the prefix sum) and no doc is padded (pad_len NULL or == L everywhere) -- the reference's
+                                 multi-view configuration, where every doc keeps d_view viewer tokens
+                                 (proj_conf/dense.yaml:31-32).  A promise by the caller, who knows the doclens on the
+                                 host; for h == 128, an fp32 index and L in {4, 8, 16} the rerank then runs a kernel
+                                 with the doc length compiled in, which does not consult the per-doc arrays at all
+                                 (bit-identical scores, ~10 % faster). */
   int32_t reserved;           /* 0 */
 } maxsim_index_view;
 
