@@ -350,6 +350,7 @@ def test_uniform_short_docs_kernel_is_bit_identical(ca, L, Lq):
     g._iv = r._index_view()
     g._iv.uniform_len = 0
     g._iv_ref = ctypes.byref(g._iv)
+    g._iv_addr = ctypes.addressof(g._iv)
     for nq, ncand in ((1, 1), (3, 7), (2, 65), (5, 1000), (300, 130), (2, 2049)):
         Q = nrm(gen, nq, Lq, h)
         cand = torch.randint(0, ndocs, (nq, ncand), generator=gen)
