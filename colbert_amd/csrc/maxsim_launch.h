@@ -87,6 +87,7 @@ int launch_stream_dense_f32(Params& p, hipStream_t st);
 // grid.  max_items = an upper bound of the list length known on the host (sizes the grid below its cap).
 int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_t st);
 int stream_list_docs_per_item(const Params& p);
+bool stream_list_serves(const Params& p, int index_dtype);
 // tu_stream_small.hip: small launches of the same kernel with each doc split over several waves (bit-identical scores).
 // MAXSIM_ERANGE = not a launch this form serves (take the regular path).
 int launch_stream_small(Params& p, int index_dtype, hipStream_t st);

@@ -1338,19 +1338,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_f32h(KARGS_DECL) {
 // uniform index (its only length bucket is L itself, colbert_ranker.py:36-40,90).
 // (one 16-column query block needs <= 96 registers: five waves per SIMD -- with 4-wave workgroups of 32 KiB that is five
 //  workgroups = 20 streams per CU instead of 16; the second launch bound asks the compiler to stay there)
-template <int WAVES, int NCB, int L, int ABLATE = 0>
-__global__ void __launch_bounds__(WAVES * 64, NCB == 1 ? 5 : 3) k_maxsim_stream_uni(KARGS_DECL) {
+// LIST: counted rows (a doc shard's share of every list): the waves walk the device-built list of wave items, as in k_maxsim_stream.
+template <int WAVES, int NCB, int L, int ABLATE = 0, bool LIST = false>
+__global__ void __launch_bounds__(WAVES * 64, NCB == 1 ? (LIST ? 4 : 5) : 3) k_maxsim_stream_uni(KARGS_DECL) {
   static_assert(L == 4 || L == 8 || L == 16, "uniform doc length: 4, 8 or 16 tokens");
   extern __shared__ __attribute__((aligned(16))) char lds[];
   KARGS_TO_PARAMS;
   constexpr int ROWB = 512, HT = 16 * ROWB, NDMA = 8, DPT = 16 / L;
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
-  int qi, chunk;
-  wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
-  const int dpwv = p.dpw / WAVES;
-  const int c_begin = chunk * p.dpw + wave * dpwv;
-  const int ndoc = max(0, min(dpwv, p.ncand - c_begin));
+  auto wave_item = [&](const int qi, const int c_begin, const int ndoc) __attribute__((always_inline)) {
   if (ndoc == 0) return;
   float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
   // descriptor lanes: lane j = first token row of the wave's j-th doc
@@ -1463,6 +1460,25 @@ __global__ void __launch_bounds__(WAVES * 64, NCB == 1 ? 5 : 3) k_maxsim_stream_
     }
   }
   if (lane < ndoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + (bad ? NEG_INF : myscore);
+  };  // wave_item
+  if constexpr (LIST) {  // (slot -> item as in k_maxsim_stream's list form: XCD x walks the x-th eighth of the list)
+    const int32_t* const wl = (const int32_t*)p.worklist;
+    const int wl_total = uni(wl[0]);
+    const int2* const wl_items = (const int2*)(wl + worklist_items_word(p.nq));
+    const int J = (wl_total + WAVES - 1) / WAVES, Jx = (J + 7) >> 3;
+    for (int s = (int)blockIdx.x; s < 8 * Jx; s += (int)gridDim.x) {
+      const int item = ((s & 7) * Jx + (s >> 3)) * WAVES + wave;
+      if ((s >> 3) >= Jx || item >= wl_total) continue;
+      const int2 e = wl_items[item];
+      wave_item(uni(e.x), uni(e.y) & ((1 << WL_SLOT_BITS) - 1), uni(e.y) >> WL_SLOT_BITS);
+    }
+  } else {
+    int qi, chunk;
+    wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
+    const int dpwv = p.dpw / WAVES;
+    const int c_begin = chunk * p.dpw + wave * dpwv;
+    wave_item(qi, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
+  }
 }
 
 }  // namespace maxsim

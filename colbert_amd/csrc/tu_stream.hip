@@ -159,6 +159,29 @@ int launch_list_v(Params& p, int max_wgs, hipStream_t st) {
 }
 }  // namespace
 
+namespace {
+template <int L>
+int launch_list_uni(Params& p, int wgs, hipStream_t st) {
+  constexpr int WAVES = 4;
+  const int ldsb = WAVES * 8192;
+  if (p.Lq <= 16) {
+    hipLaunchKernelGGL((k_maxsim_stream_uni<WAVES, 1, L, 0, true>), dim3((unsigned)wgs), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  } else {
+    hipLaunchKernelGGL((k_maxsim_stream_uni<WAVES, 2, L, 0, true>), dim3((unsigned)wgs), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  }
+  return check_launch();
+}
+}  // namespace
+
+// Does the list form serve this index?  Docs longer than 24 tokens on average: the general kernel; shorter: only the
+// uniform 4 / 8 / 16-token kernel on an fp32 index (ragged short docs keep the static grid and its half-tile kernel).
+bool stream_list_serves(const Params& p, int index_dtype) {
+  const bool short_docs = p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs;
+  if (!short_docs) return true;
+  return index_dtype == MAXSIM_F32 && (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16) &&
+         p.n_tokens == (int64_t)p.uniform_len * p.n_docs;
+}
+
 int stream_list_docs_per_item(const Params& p) {
   double avg = p.n_docs > 0 ? (double)p.n_tokens / (double)p.n_docs : 1.0;
   if (avg < 1.0) avg = 1.0;
@@ -176,6 +199,11 @@ int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_
   if (wgs < 1) wgs = 1;
   if (wgs > cap) wgs = cap;
   wgs = (wgs + 7) & ~(int64_t)7;  // the kernel's slot -> item map assumes a workgroup's slots share s % 8
+  if (p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs) {  // (stream_list_serves: a uniform short-doc fp32 index)
+    if (p.uniform_len == 8) return launch_list_uni<8>(p, (int)wgs, st);
+    if (p.uniform_len == 4) return launch_list_uni<4>(p, (int)wgs, st);
+    return launch_list_uni<16>(p, (int)wgs, st);
+  }
   if (p.Lq <= 16 && index_dtype == MAXSIM_F32) return launch_list_v<MAXSIM_F32, 16>(p, (int)wgs, st);
   switch (index_dtype) {
     case MAXSIM_F32: return launch_list_v<MAXSIM_F32, QT_2X16>(p, (int)wgs, st);

@@ -45,14 +45,18 @@ def _counted_rows(gen, nq, ncand, ndocs, counts):
     dict(dtype=torch.float32, mode="fast", Lq=32, lo=30, hi=180, nq=12, ncand=150),
     dict(dtype=torch.float16, mode="exact", Lq=32, lo=25, hi=180, nq=20, ncand=260),     # the reference's storage dtype
     dict(dtype=torch.bfloat16, mode="exact", Lq=32, lo=25, hi=180, nq=10, ncand=128),
-    dict(dtype=torch.float32, mode="exact", Lq=32, lo=1, hi=12, nq=8, ncand=100),        # short docs: static grid fallback
+    dict(dtype=torch.float32, mode="exact", Lq=32, lo=1, hi=12, nq=8, ncand=100),        # ragged short docs: static grid fallback
+    dict(dtype=torch.float32, mode="exact", Lq=8, lo=8, hi=8, nq=40, ncand=500),         # uniform 8-token docs: the fixed-length list kernel
+    dict(dtype=torch.float32, mode="exact", Lq=40, lo=16, hi=16, nq=9, ncand=130),       # uniform 16, two blocks, query slices
+    dict(dtype=torch.float32, mode="exact", Lq=20, lo=4, hi=4, nq=12, ncand=300),        # uniform 4
     dict(dtype=torch.float16, mode="exact", Lq=32, lo=10, hi=60, nq=6, ncand=70, h=768), # wide rows: static grid fallback
 ], ids=lambda c: f"{str(c['dtype']).split('.')[-1]}-{c['mode']}-Lq{c['Lq']}-h{c.get('h', 128)}-{c['lo']}_{c['hi']}")
 def test_counted_rows_equal_full_width_rows(ca, cfg):
     gen = torch.Generator().manual_seed(31)
     h, ndocs, nq, ncand = cfg.get("h", 128), 500, cfg["nq"], cfg["ncand"]
     doclens = torch.randint(cfg["lo"], cfg["hi"] + 1, (ndocs,), generator=gen).tolist()
-    doclens[7] = 0                                                                       # an empty doc scores 0
+    if cfg["lo"] != cfg["hi"]:
+        doclens[7] = 0                                                                   # an empty doc scores 0 (not in a uniform index)
     emb = nrm(gen, sum(doclens), h).to(cfg["dtype"])
     r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=cfg["dtype"], fp32_mode=cfg["mode"])
     counts = torch.randint(0, ncand + 1, (nq,), generator=gen)
@@ -67,7 +71,8 @@ def test_counted_rows_equal_full_width_rows(ca, cfg):
         full = r.score_candidates(Q, cand.cuda(), **kw)
         cnt = r.score_candidates(Q, cand.cuda(), cand_count=counts.cuda(), **kw)
         assert torch.equal(full.cpu(), cnt.cpu())                                        # incl. the -inf tails
-        assert bool(torch.isinf(cnt[0]).all()) and float(cnt[1, 3]) == 0.0 and float(cnt[1, 5]) == float("-inf")
+        assert bool(torch.isinf(cnt[0]).all()) and float(cnt[1, 5]) == float("-inf")
+        assert cfg["lo"] == cfg["hi"] or float(cnt[1, 3]) == 0.0
     for k in (1, 10, ncand):
         p0, s0 = r.topk(full, cand.cuda(), k)
         p1, s1 = r.topk(cnt, cand.cuda(), k, counts.cuda())
