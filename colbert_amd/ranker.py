@@ -116,6 +116,8 @@ class ColbertRanker:
         self.parts_doclens = parts_doclens
         self.model = model
         self.device = torch.device(device)
+        if self.device.type == "cuda" and self.device.index is None:          # "cuda" -> the current device, spelled out: tensors
+            self.device = torch.device("cuda", torch.cuda.current_device())   # report cuda:N, and rank_forward compares devices
         assert fp32_mode in ("exact", "fast", "bf16x3")
         self.fp32_mode = fp32_mode
         doclens = [int(x) for y in parts_doclens for x in y]                  # flatten, utils.py:133

@@ -288,8 +288,19 @@ def test_rank_forward_equals_batched_entry_points(ca, dtype, Lq):
     doclens = torch.randint(100, 301, (ndocs,), generator=gen).tolist()            # long enough for the split form (fp16 / bf16)
     emb = nrm(gen, sum(doclens), h).to(dtype)
     r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=dtype)
+    assert r.device.index is not None                    # "cuda" is spelled out, so the caller's cuda:N tensors compare equal
     q = nrm(gen, Lq, h)
     Q = q.unsqueeze(0).permute(0, 2, 1)
+    # the reference-shaped call (list of pids, permuted view of a contiguous fp32 q on the index's device) goes straight to
+    # the C glue; every other form through the general preamble: same lists
+    pl = torch.randint(0, ndocs, (500,), generator=gen).tolist()
+    fast = r.rank_forward(Q.cuda(), pl, depth=50)
+    r._fast_ok = False
+    try:
+        assert r.rank_forward(Q.cuda(), pl, depth=50) == fast
+    finally:
+        r._fast_ok = True
+    assert r.rank_forward(Q, pl, depth=50) == fast and r.rank_forward(Q.cuda().contiguous(), pl, depth=50) == fast
     for n in (1, 2, 15, 16, 17, 100, 333, 1000, 1000, 2047, 2048, 2049, 3000, 7):
         pids = torch.randint(0, ndocs, (n,), generator=gen).tolist()                # duplicates allowed: equal scores, tie order by position
         for depth in (1, 10, n, n + 5):
