@@ -410,7 +410,7 @@ static int topk_impl(const float* scores, const int64_t* pids, const int32_t* co
   if (rc) return rc;
   int threads = P / 2 < 64 ? 64 : (P / 2 > 1024 ? 1024 : P / 2);
   hipLaunchKernelGGL(k_topk, dim3((unsigned)nq), dim3(threads), ldsb, (hipStream_t)stream, scores, pids, ncand, k,
-                     P, out_scores, out_pids);
+                     P, out_scores, out_pids, counts);
   return check_launch();
 }
 

@@ -108,16 +108,26 @@ __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ sc
 // =============================================================================================
 // Long lists (2048 < ncand <= 16384 = the reference's BSIZE): bitonic sort of the keys in LDS, one workgroup per query.
 // =============================================================================================
+// counts (optional): counted rows -- only the first counts[q] slots of row q are candidates (the rest is (-inf, -1) padding,
+// which is also what the output slots past them receive): the row is sorted as the next power of two >= its count, e.g. a
+// 16384-wide row of ANN pids with ~2000 distinct candidates as 2048 keys (36 exchange stages instead of 105).
 __global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores, const int64_t* __restrict__ pids,
                                                int ncand, int k, int P, float* __restrict__ out_s,
-                                               int64_t* __restrict__ out_p) {
+                                               int64_t* __restrict__ out_p, const int32_t* __restrict__ counts) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   uint64_t* keys = (uint64_t*)lds;  // [P]
   const int q = blockIdx.x;
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int row_w = ncand;
+  if (counts) {
+    ncand = min(max(counts[q], 0), row_w);
+    int Pq = 2;
+    while (Pq < ncand) Pq <<= 1;
+    P = min(P, Pq);
+  }
   for (int i = tid; i < P; i += nt) {
     uint64_t key = 0;  // below every real key (orderable(-inf) = 0x007fffff > 0)
-    if (i < ncand) key = ((uint64_t)orderable(scores[(int64_t)q * ncand + i]) << 32) | (uint32_t)(~(uint32_t)i);
+    if (i < ncand) key = ((uint64_t)orderable(scores[(int64_t)q * row_w + i]) << 32) | (uint32_t)(~(uint32_t)i);
     keys[i] = key;
   }
   __syncthreads();
@@ -141,7 +151,7 @@ __global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores,
       uint64_t key = keys[i];
       int pos = (int)(~(uint32_t)key);
       s = unorderable((uint32_t)(key >> 32));
-      pid = pids ? pids[(int64_t)q * ncand + pos] : (int64_t)pos;
+      pid = pids ? pids[(int64_t)q * row_w + pos] : (int64_t)pos;
     }
     out_s[(int64_t)q * k + i] = s;
     out_p[(int64_t)q * k + i] = pid;

@@ -279,7 +279,8 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
  *   of an 8-way sharded step then costs what the same docs cost as dense rows.  Other shapes take maxsim_rerank_ex's path.
  *   worklist: 16-byte aligned device scratch of maxsim_worklist_bytes(nq, ncand) bytes (contents need not survive the
  *   call; NULL or too small = maxsim_rerank_ex's path).  ncand < 2^20 for the list form.
- * maxsim_topk_counted: maxsim_topk that ranks the live slots only (ncand <= 2048; longer rows ignore the counts).
+ * maxsim_topk_counted: maxsim_topk that ranks the live slots only (rows longer than 2048: sorted as the next power of
+ *   two >= the row's count instead of >= its width).
  */
 int64_t maxsim_worklist_bytes(int nq, int ncand);
 int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,

@@ -109,6 +109,29 @@ def test_counted_rows_on_wide_embeddings(ca, dtype, qdtype, h, Lq):
         assert torch.equal(r.score_candidates(Q2, cd.cuda()).cpu(), r.score_candidates(Q2, cd.cuda(), cand_count=c2.cuda()).cpu())
 
 
+def test_counted_topk_on_long_rows(ca):
+    """Rows longer than 2048 slots (ANN pid lists: up to 16384 = the reference's BSIZE) with a live count: the sort kernel
+    works on the next power of two >= the count; same lists as the uncounted top-k, incl. ties, k > count and count = 0."""
+    gen = torch.Generator().manual_seed(8)
+    nq, n = 9, 5000
+    counts = torch.tensor([0, 1, 2, 3, 1000, 2047, 2048, 2049, 5000], dtype=torch.int32)
+    scores = torch.full((nq, n), float("-inf"))
+    pids = torch.full((nq, n), -1, dtype=torch.int64)
+    for q in range(nq):
+        c = int(counts[q])
+        scores[q, :c] = torch.randint(0, 50, (c,), generator=gen).float() / 7        # heavy ties
+        pids[q, :c] = torch.randperm(100000, generator=gen)[:c]
+    lib = ca._lib.lib
+    st = torch.cuda.current_stream().cuda_stream
+    sc, pc, cc = scores.cuda(), pids.cuda(), counts.cuda()
+    for k in (1, 100, 3000):
+        o = [torch.empty(nq, k, device="cuda"), torch.empty(nq, k, dtype=torch.int64, device="cuda"),
+             torch.empty(nq, k, device="cuda"), torch.empty(nq, k, dtype=torch.int64, device="cuda")]
+        assert lib.maxsim_topk(sc.data_ptr(), pc.data_ptr(), nq, n, k, o[0].data_ptr(), o[1].data_ptr(), st) == 0
+        assert lib.maxsim_topk_counted(sc.data_ptr(), pc.data_ptr(), cc.data_ptr(), nq, n, k, o[2].data_ptr(), o[3].data_ptr(), st) == 0
+        assert torch.equal(o[0].cpu(), o[2].cpu()) and torch.equal(o[1].cpu(), o[3].cpu()), k
+
+
 def test_counted_rows_small_and_large_launches(ca):
     """The builder picks the docs per wave item ON THE DEVICE from the number of live candidates: a launch with few of
     them gets shorter items (more waves), one with many the ~1.4 k-token streams.  Both ends against the static grid."""
