@@ -314,6 +314,7 @@ def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32
                                    "pmc_source", "mfma_busy_frac", "mfma_tflops")})
     if online_call:     # the reference's online call on this index (its storage dtype): one rank_forward per query
         out["single_query"] = single_query_probe(ranker, Q, cands, h, lq, esize)
+        out["batched_retrieve_step"] = retrieve_step_probe(ranker, Q, dev)
     return out, (idx, doclens)
 
 
@@ -603,6 +604,38 @@ def main():
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     if use_dist:
         dist.destroy_process_group()
+
+
+def retrieve_step_probe(ranker, Q, dev, faiss_depth=512, hot=1500):
+    """The batched driver's step after the ANN search (the reference: per query `emb2pid` + `set()` in a
+    Pool(16), then rank_forward -- colbert_ranker.py:212-229, dense_server_client.py:44-48): 256 queries x (32 tokens x
+    faiss_depth) synthetic ANN ids that cluster on ~1500 docs per query -> distinct pids (counted rows, nothing read
+    back) -> counted rerank -> counted top-100.  HIP events around each of the three launches' groups, 8 repetitions."""
+    nq, nd = Q.size(0), ranker.n_docs
+    n = Q.size(1) * faiss_depth
+    g = torch.Generator(device=dev).manual_seed(7)
+    docs = torch.randint(0, nd, (nq, hot), generator=g, device=dev)
+    L = int(ranker.d_doclens[0].item())
+    ids = docs.gather(1, torch.randint(0, hot, (nq, n), generator=g, device=dev)) * L + torch.randint(0, L, (nq, n), generator=g, device=dev)
+
+    def t(f, k=8):
+        for _ in range(2):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(k):
+            f()
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) / k
+    cand, cnt = ranker.embedding_ids_to_pids(ids, trim=False)
+    sc = ranker.score_candidates(Q, cand, cand_count=cnt)
+    a = t(lambda: ranker.embedding_ids_to_pids(ids, trim=False))
+    b = t(lambda: ranker.score_candidates(Q, cand, cand_count=cnt))
+    c = t(lambda: ranker.topk(sc, cand, TOPK, cnt))
+    return {"shape": f"{nq} queries x {n} ANN ids (faiss_depth {faiss_depth}), {float(cnt.float().mean()):.0f} distinct candidates per query",
+            "ids_to_pids_ms": round(a, 4), "counted_rerank_ms": round(b, 4), "counted_topk_ms": round(c, 4),
+            "step_ms": round(a + b + c, 4), "queries_per_s": round(nq / ((a + b + c) * 1e-3), 1)}
 
 
 def single_query_probe(ranker, Q, cands, H, LQ, esize):
