@@ -182,6 +182,19 @@ def test_shard_candidates_cpu_partition_is_stable():
     assert gp.tolist() == [[5, 3, 4, -1, -1], [4, 4, 5, -1, -1]]
 
 
+def test_shard_candidates_cpu_counts_and_single_process_checks():
+    """The per-row live counts the counted rerank is scheduled from (CPU form of maxsim_shard_candidates' out_count), and
+    the stride agreement check as a no-op without a process group."""
+    from colbert_amd.sharded import assert_strides_agree, shard_candidates
+    c = torch.tensor([[0, 5, 9, 3, 4], [4, 4, 2, 8, 5], [9, 9, 9, 9, 9]])
+    loc, gp, cnt = shard_candidates(c, 3, 6, with_counts=True)
+    assert cnt.dtype == torch.int32 and cnt.tolist() == [3, 3, 0]
+    assert loc.tolist() == [[2, 0, 1, -1, -1], [1, 1, 2, -1, -1], [-1] * 5]
+    for q in range(3):                                   # the counted-rows precondition: live first, negative behind
+        assert bool((loc[q, :cnt[q]] >= 0).all()) and bool((loc[q, cnt[q]:] < 0).all())
+    assert_strides_agree([8, 20, 180])                   # no process group: nothing to compare (world 2: the gloo test above)
+
+
 def test_shard_range_and_localize():
     from colbert_amd.sharded import localize, merge_gathered, shard_range
     assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
