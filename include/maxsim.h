@@ -272,11 +272,13 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
  * are its first cand_count[q] slots and every slot after them holds a negative pid (what those two functions write).
  * Results are then identical to maxsim_rerank_ex / maxsim_topk on the same matrices; what changes is the schedule:
  *
- * maxsim_rerank_counted: for h == 128 (any index dtype, docs longer than 24 tokens on average) the device builds a dense
- *   list of wave-sized work items from the counts (two small kernels: a scan and a fill, which also writes the -inf
- *   tail of `scores`) and the streaming kernel runs as a fixed grid whose waves walk that list -- no host
- *   synchronisation to size the launch, no all-padding workgroups, every wave of every workgroup busy.  One rank's share
- *   of an 8-way sharded step then costs what the same docs cost as dense rows.  Other shapes take maxsim_rerank_ex's path.
+ * maxsim_rerank_counted: the device builds a dense list of work items from the counts (two small kernels: a scan and a
+ *   fill, which also writes the -inf tail of `scores`) and the streaming kernel runs as a fixed grid that walks that list
+ *   -- no host synchronisation to size the launch, no all-padding workgroups, every wave of every workgroup busy.  One
+ *   rank's share of an 8-way sharded step then costs what the same docs cost as dense rows.  Served: h == 128 with docs
+ *   longer than 24 tokens on average (any index dtype; wave-sized items) or a uniform 4 / 8 / 16-token fp32 index
+ *   (uniform_len); 128 < h <= 1024 in multiples of 128 (workgroup-sized items: the waves share the staged query).
+ *   Other shapes take maxsim_rerank_ex's path.
  *   worklist: 16-byte aligned device scratch of maxsim_worklist_bytes(nq, ncand) bytes (contents need not survive the
  *   call; NULL or too small = maxsim_rerank_ex's path).  ncand < 2^20 for the list form.
  * maxsim_topk_counted: maxsim_topk that ranks the live slots only (rows longer than 2048: sorted as the next power of
