@@ -424,3 +424,37 @@ def test_uniform_promise_only_for_uniform_unpadded_indexes(ca):
     assert r._iv.uniform_len == 0
     rag = ca.ColbertRanker(parts=[emb], parts_doclens=[[8] * 49 + [4, 4]], dim=128, index_dtype=torch.float32)
     assert rag._iv.uniform_len == 0
+
+
+# ------------------------------------------------------------------------------------------------------
+# the stride collectives of the sharded path on RCCL (backend "nccl"), as far as one GPU allows
+# ------------------------------------------------------------------------------------------------------
+def test_stride_sync_collectives_run_on_rccl(ca, monkeypatch):
+    """`global_strides` / `assert_strides_agree` issue their all_reduces on CUDA tensors when the backend is nccl (= RCCL).
+    A one-GPU box cannot hold two RCCL ranks, so this runs them on a world-1 RCCL group with the world size reported as
+    2 (the `> 1` guards would skip them otherwise): placement, dtypes and the results' way back to the host are exercised;
+    the multi-rank semantics are covered by the world-2 gloo test."""
+    import socket
+    import torch.distributed as dist
+    from colbert_amd import sharded
+    from colbert_amd.ranker import reference_strides
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        monkeypatch.setattr(sharded.dist, "get_world_size", lambda group=None: 2)
+        gen = torch.Generator().manual_seed(6)
+        doclens = torch.randint(1, 181, (500,), generator=gen)
+        gs = sharded.global_strides(doclens)                                  # all_reduce(MAX) + all_reduce(SUM) on cuda tensors
+        assert gs == reference_strides(doclens)
+        sharded.assert_strides_agree(gs)                                      # all_reduce(MAX) of (strides, -strides)
+        emb = nrm(gen, int(doclens.sum()), 128).half()
+        r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens.tolist()], dim=128)
+        sr = sharded.ShardedRanker(r, 0, 500)                                 # the shipped constructor: both, then set_strides
+        assert r.strides == gs and sr._world() == 2
+    finally:
+        monkeypatch.undo()
+        dist.destroy_process_group()
