@@ -623,7 +623,6 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   // ---- query tile -> registers in MFMA B layout --------------------------------------------------------------
   // fp32: lane (n, hh) holds Q[n][32 s + 8 u + 4 hh + t]   in qv[4 s + u][t]
   // 16b : lane (n, hh) holds Q[n][16 i + 8 hh + j], j=0..7 in qp[piece][i] (packed pairs)
-  constexpr bool F16Q = (DT == MAXSIM_F16 || DT == F32S);  // query split into fp16 hi + 2^-11 lo
   f32x4 qv[DT == MAXSIM_F32 ? 16 : 1];
   u32x4 qp[DT == MAXSIM_F32 ? 1 : NP][DT == MAXSIM_F32 ? 1 : 8];
   // QSTAGE (small launches: every workgroup of the launch wants the SAME one or few query tiles at the same moment): the
@@ -634,23 +633,87 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   constexpr bool QSTAGE = QFIRST;
   constexpr int QS_ROW = 132;  // floats per staged row: 512 B + 16 B of padding (bank spread of the 16 token rows)
   const float* const lds_q = (const float*)lds;
+  constexpr bool F16Q = (DT == MAXSIM_F16 || DT == F32S);  // query split into fp16 hi + 2^-11 lo
+  // eight consecutive query dims -> this index type's NP 16-bit pieces, packed in pairs (what a lane holds per k-group)
+  auto split_pack = [&](const float (&q)[8], u32x4 (&w)[DT == MAXSIM_F32 ? 1 : NP]) __attribute__((always_inline)) {
+    uint16_t pc[DT == MAXSIM_F32 ? 1 : NP][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = q[j];
+      if constexpr (DT == MAXSIM_F32) {
+        pc[0][j] = 0;
+      } else if constexpr (DT == F32X) {  // exact truncation split: x = t0 + t1 + t2
+        const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
+        const float r1 = x - __uint_as_float(u0);
+        const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
+        const float r2 = r1 - __uint_as_float(u1);
+        pc[0][j] = (uint16_t)(u0 >> 16);
+        pc[1][j] = (uint16_t)(u1 >> 16);
+        pc[NP - 1][j] = (uint16_t)(__float_as_uint(r2) >> 16);
+      } else if constexpr (F16Q) {
+        _Float16 hi = (_Float16)x;
+        _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+        __builtin_memcpy(&pc[0][j], &hi, 2);
+        __builtin_memcpy(&pc[1][j], &lo, 2);
+      } else {
+        uint16_t b0 = f32_to_bf16_rn(x);
+        float r1 = x - bf16_to_f32(b0);
+        uint16_t b1 = f32_to_bf16_rn(r1);
+        float r2 = r1 - bf16_to_f32(b1);
+        pc[0][j] = b0;
+        pc[1][j] = b1;
+        pc[NP - 1][j] = f32_to_bf16_rn(r2);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < (DT == MAXSIM_F32 ? 1 : NP); ++k)
+#pragma unroll
+      for (int y = 0; y < 4; ++y) w[k][y] = (uint32_t)pc[k][2 * y] | ((uint32_t)pc[k][2 * y + 1] << 16);
+  };
   if constexpr (QSTAGE) {
     int qlen0 = p.Lq;
     if (MODE == MODE_RERANK && p.q_len) qlen0 = min(qlen0, p.q_len[qi]);
     const bool qf32s = p.q_dtype == MAXSIM_F32;
-    for (int c = threadIdx.x; c < 32 * 32; c += WAVES * 64) {
-      const int row = c >> 5, chunk = c & 31;
-      const int tokq = p.q_tok0 + row;
-      const bool lv = q_token_live<MODE>(p, qi, tokq, qlen0);
-      const int64_t src = ((int64_t)qi * p.Lq + (lv ? tokq : 0)) * 128 + 4 * chunk;
-      f32x4 v;
-      if (qf32s) {
-        v = *(const f32x4*)((const float*)p.Q + src);
-      } else {
+    if constexpr (DT == MAXSIM_F32) {  // the fp32 image, row-major (each wave gathers its layout from it)
+      for (int c = threadIdx.x; c < 32 * 32; c += WAVES * 64) {
+        const int row = c >> 5, chunk = c & 31;
+        const int tokq = p.q_tok0 + row;
+        const bool lv = q_token_live<MODE>(p, qi, tokq, qlen0);
+        const int64_t src = ((int64_t)qi * p.Lq + (lv ? tokq : 0)) * 128 + 4 * chunk;
+        f32x4 v;
+        if (qf32s) {
+          v = *(const f32x4*)((const float*)p.Q + src);
+        } else {
 #pragma unroll
-        for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, src + t);
+          for (int t = 0; t < 4; ++t) v[t] = load_q(p.Q, p.q_dtype, src + t);
+        }
+        *(f32x4*)((float*)lds + row * QS_ROW + 4 * chunk) = lv ? v : (f32x4)(0.0f);
       }
-      *(f32x4*)((float*)lds + row * QS_ROW + 4 * chunk) = lv ? v : (f32x4)(0.0f);
+    } else {
+      // 16-bit index: the pieces are split ONCE per workgroup and staged in their final per-lane order -- entry (piece k,
+      // k-group i, lane) at [(8 k + i) * 64 + lane] -- so a wave's query registers are NP * 8 ds_read_b128, no VALU
+      // (every wave splitting the same 32 x 128 values itself: ~400 VALU per wave at the head of a ~13 us kernel)
+      for (int e = threadIdx.x; e < 8 * 64; e += WAVES * 64) {
+        const int i = e >> 6, ln = e & 63;
+        const int tok16 = p.q_tok0 + 16 * (i >> 2) + (ln & 15);
+        const bool lv = q_token_live<MODE>(p, qi, tok16, qlen0);
+        const int64_t e0 = ((int64_t)qi * p.Lq + (lv ? tok16 : 0)) * 128 + 8 * (4 * (i & 3) + (ln >> 4));
+        float q[8];
+        if (qf32s) {
+          const f32x4 v0 = *(const f32x4*)((const float*)p.Q + e0), v1 = *(const f32x4*)((const float*)p.Q + e0 + 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { q[j] = v0[j]; q[4 + j] = v1[j]; }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) q[j] = load_q(p.Q, p.q_dtype, e0 + j);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = lv ? q[j] : 0.0f;
+        u32x4 w[DT == MAXSIM_F32 ? 1 : NP];
+        split_pack(q, w);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) ((u32x4*)lds)[(8 * k + i) * 64 + ln] = w[k];
+      }
     }
     __syncthreads();
   }
@@ -715,14 +778,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
           lv = q_token_live<MODE>(p, qi, tok16, qlen);
           e0 = ((int64_t)qi * p.Lq + (lv ? tok16 : 0)) * 128 + 8 * (4 * (i & 3) + (lane >> 4));
         }
-        float q[8];
-        if constexpr (QSTAGE && QT == QT_2X16) {
-          const float* const ql = lds_q + (16 * (i >> 2) + (lane & 15)) * QS_ROW + 8 * (4 * (i & 3) + (lane >> 4));
-          const f32x4 v0 = *(const f32x4*)ql, v1 = *(const f32x4*)(ql + 4);
+        if constexpr (QSTAGE && QT == QT_2X16) {  // staged in final order by the workgroup (above)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { q[j] = v0[j]; q[4 + j] = v1[j]; }
-          lv = true;
-        } else if (qf32) {
+          for (int k = 0; k < NP; ++k) qp[k][i] = ((const u32x4*)lds)[(8 * k + i) * 64 + lane];
+          continue;
+        }
+        float q[8];
+        if (qf32) {
           const f32x4 v0 = *(const f32x4*)((const float*)p.Q + e0);
           const f32x4 v1 = *(const f32x4*)((const float*)p.Q + e0 + 4);
 #pragma unroll
@@ -731,37 +793,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 #pragma unroll
           for (int j = 0; j < 8; ++j) q[j] = load_q(p.Q, p.q_dtype, e0 + j);
         }
-        uint16_t pc[NP][8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float x = lv ? q[j] : 0.0f;
-          if constexpr (DT == F32X) {  // exact truncation split: x = t0 + t1 + t2
-            const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
-            const float r1 = x - __uint_as_float(u0);
-            const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
-            const float r2 = r1 - __uint_as_float(u1);
-            pc[0][j] = (uint16_t)(u0 >> 16);
-            pc[1][j] = (uint16_t)(u1 >> 16);
-            pc[NP - 1][j] = (uint16_t)(__float_as_uint(r2) >> 16);
-          } else if constexpr (F16Q) {
-            _Float16 hi = (_Float16)x;
-            _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
-            __builtin_memcpy(&pc[0][j], &hi, 2);
-            __builtin_memcpy(&pc[1][j], &lo, 2);
-          } else {
-            uint16_t b0 = f32_to_bf16_rn(x);
-            float r1 = x - bf16_to_f32(b0);
-            uint16_t b1 = f32_to_bf16_rn(r1);
-            float r2 = r1 - bf16_to_f32(b1);
-            pc[0][j] = b0;
-            pc[1][j] = b1;
-            pc[NP - 1][j] = f32_to_bf16_rn(r2);
-          }
-        }
+        for (int j = 0; j < 8; ++j) q[j] = lv ? q[j] : 0.0f;
+        u32x4 w[DT == MAXSIM_F32 ? 1 : NP];
+        split_pack(q, w);
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-#pragma unroll
-          for (int w = 0; w < 4; ++w) qp[k][i][w] = (uint32_t)pc[k][2 * w] | ((uint32_t)pc[k][2 * w + 1] << 16);
+        for (int k = 0; k < NP; ++k) qp[k][i] = w[k];
       }
     }
   }
