@@ -306,6 +306,10 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
       if (rc != MAXSIM_ERANGE) return rc;
       p.worklist = nullptr;  // (not reached: bigh_list_waves said the form serves this launch)
     }
+    if (Lq <= 32) {  // small launches (the online call): docs split over several waves
+      const int rc = launch_bigh_rerank_small(p, dt, st);
+      if (rc != MAXSIM_ERANGE) return rc;
+    }
     int rc = for_query_slices(p, [&] { return launch_bigh_rerank(p, dt, st); });
     if (rc != MAXSIM_ERANGE) return rc;
   }

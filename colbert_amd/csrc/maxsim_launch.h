@@ -95,6 +95,9 @@ int launch_stream_small(Params& p, int index_dtype, hipStream_t st);
 // Return MAXSIM_ERANGE when the query image does not fit in LDS.
 int launch_bigh_rerank(Params& p, int dt, hipStream_t st);
 int launch_bigh_dense(Params& p, int dt, bool argmax, hipStream_t st);
+// tu_bigh_rerank_small.hip: small launches of the same kernel with each doc split over 2 / 4 waves (bit-identical scores).
+// MAXSIM_ERANGE = not a launch this form serves (take the regular path).
+int launch_bigh_rerank_small(Params& p, int dt, hipStream_t st);
 // tu_bigh_rerank_list.hip: the same kernel walking a work list of WORKGROUP items (counted rows; maxsim_worklist.h).
 // bigh_list_waves: waves per workgroup of that form for this launch, 0 = not served.
 int bigh_list_waves(const Params& p, int dt);

@@ -23,9 +23,13 @@
 namespace maxsim {
 
 // Reduction state for QB queries that walk the same documents (dense mode), optionally with arg-max tracking.
-template <int QB, bool AM>
+// SPLIT (small launches, QB = 1): a doc is streamed by several waves, each a slice of its tokens; a finished slice PARKS its
+// per-query-token maxima in a register (parked[doc ordinal], lanes = query tokens) instead of finishing the score -- the
+// workgroup combines the slices after the stream (k_maxsim_stream_bigh).
+template <int QB, bool AM, bool SPLIT = false>
 struct MultiReducer {
   float rmax[QB], myscore[QB];
+  float parked[SPLIT ? SPLIT_MAX_DOCS : 1];
   int ridx[QB];
   int jdoc;
   __device__ __forceinline__ void init() {
@@ -35,10 +39,22 @@ struct MultiReducer {
       myscore[x] = 0.0f;
       ridx[x] = 0;
     }
+#pragma unroll
+    for (int k = 0; k < (SPLIT ? SPLIT_MAX_DOCS : 1); ++k) parked[k] = NEG_INF;
     jdoc = 0;
   }
   // argdoc[x]: &argmax[(query x, this doc) * Lq] (AM only)
   __device__ __forceinline__ void finish_doc(const Cursor& C, int lane, int32_t* const (&argdoc)[QB], int Lq) {
+    if constexpr (SPLIT) {  // both lane halves -> the token's maximum over this slice, parked under the doc's ordinal
+      const uint32_t xb = __float_as_uint(rmax[0]);
+      const auto sw = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+      const float v = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+#pragma unroll
+      for (int k = 0; k < SPLIT_MAX_DOCS; ++k) parked[k] = (jdoc == k && C.kind == 0) ? v : parked[k];
+      rmax[0] = NEG_INF;
+      ++jdoc;
+      return;
+    }
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
       float sc;
@@ -134,9 +150,13 @@ struct MultiReducer {
 // the doc fetch never leaves the row (issue_rows<PART>).
 // LIST (counted candidate rows, maxsim_worklist.h): a fixed grid whose WORKGROUPS walk the device-built list of workgroup
 //   items (query, first slot, docs); an item's docs are dealt evenly over the waves, the query image is staged per item.
-template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false>
+// SPLITK (small launches -- the reference's online call is ONE query x ~1000 docs): a doc is streamed by p.split (2 or 4)
+//   waves of the workgroup, each a slice of whole 32-row tiles.  With one wave per doc the launch lasts as long as its
+//   LONGEST doc takes one wave (dim 768: 384 tokens = 72 sub-tiles of ~1.5 us), whatever the average.
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false, bool SPLITK = false>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   static_assert(!LIST || (MODE == MODE_RERANK && QB == 1 && !AM), "work-list form: rerank, one query per workgroup");
+  static_assert(!SPLITK || (MODE == MODE_RERANK && QB == 1 && !AM && !LIST && !PART), "split form: static-grid rerank");
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
   static_assert(!AM || MODE == MODE_DENSE, "arg-max tracking is a dense (training-form) feature");
   static_assert(QB == 1 || MODE == MODE_DENSE, "several queries share documents only in the all-pairs form");
@@ -152,8 +172,16 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   const int lane = threadIdx.x & 63;
   const int wave = uni(threadIdx.x >> 6);
   // one workgroup item: the wave's candidates [c_begin, c_begin + ndoc) of the queries q0 .. q0 + QB - 1
+  const int split = SPLITK ? p.split : 1;
+  const int team = SPLITK ? wave / split : wave, part = SPLITK ? wave - team * split : 0;
   auto wg_item = [&](const int q0, const int c_begin, const int ndoc) __attribute__((always_inline)) {
-  const DocLanes dl = load_doc_lanes<MODE>(p, q0, c_begin, ndoc, lane);
+  DocLanes dl = load_doc_lanes<MODE>(p, q0, c_begin, ndoc, lane);
+  if constexpr (SPLITK) {  // this wave's slice of every doc: whole 32-row tiles, cut as evenly as possible
+    const int per = (((dl.len + 31) >> 5) + split - 1) / split * 32;
+    const int start = min(dl.len, part * per);
+    dl.row0 += (uint32_t)start;
+    dl.len = min(dl.len - start, per);  // may be 0: the slice then parks -inf maxima (neutral)
+  }
   const int qimg = NPQ * KB * SUB;                          // one query's image: [NPQ][KB][32 rows][BLKB]
   char* const qlds = lds;
   char* const wlds = lds + QB * qimg + wave * (NT * SUB);
@@ -244,7 +272,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   }
   __syncthreads();  // the only workgroup barrier: the query images are read-only from here on
 
-  MultiReducer<QB, AM> red;
+  MultiReducer<QB, AM, SPLITK> red;
   red.init();
   int32_t* argq[QB];
 #pragma unroll
@@ -345,6 +373,43 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
     ++nconsumed;
   }
   red.drain(C, dl, lane, argq, p.Lq);
+  if constexpr (SPLITK) {
+    // the slices meet: every wave writes its parked maxima ([doc ordinal][32 query tokens]) to its own, now idle, ring;
+    // wave `part == 0` of a team combines them doc by doc: max over the slices, then exactly the unsplit wave's floor
+    // + sum tree (bit-identical scores)
+    float* const mine = (float*)wlds;
+#pragma unroll
+    for (int k = 0; k < SPLIT_MAX_DOCS; ++k)
+      if (lane < 32) mine[k * 32 + lane] = red.parked[k];
+    __syncthreads();
+    if (part == 0) {
+      float my = 0.0f;
+      for (int j = 0; j < ndoc; ++j) {
+        const int fl = __builtin_amdgcn_readlane(dl.flags, j);
+        float sc;
+        if ((fl & 3) == 0) {
+          float v = NEG_INF;
+          for (int sp = 0; sp < split; ++sp)
+            v = fmaxf(v, ((const float*)(lds + QB * qimg + (wave + sp) * (NT * SUB)))[j * 32 + (lane & 31)]);
+          if (fl >> 2) v = fmaxf(v, 0.0f);
+          v += dpp_f32<0xB1>(v);
+          v += dpp_f32<0x4E>(v);
+          v += dpp_f32<0x141>(v);
+          v += dpp_f32<0x140>(v);
+          sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 0)) +
+               __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(v), 16));
+        } else {
+          sc = (fl & 3) == 1 ? 0.0f : NEG_INF;
+        }
+        my = (lane == j) ? sc : my;
+      }
+      if (lane < ndoc) {
+        float* const cell = p.scores + (int64_t)q0 * p.ncand + c_begin + lane;
+        *cell = (p.accum ? *cell : 0.0f) + my;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int x = 0; x < QB; ++x)
     if (lane < red.jdoc && q0 + x < p.nq) {
@@ -376,8 +441,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       qblk = blockIdx.x / p.nchunk;
       chunk = blockIdx.x - qblk * p.nchunk;
     }
-    const int dpwv = p.dpw / WAVES;
-    const int c_begin = chunk * p.dpw + wave * dpwv;
+    const int dpwv = SPLITK ? p.dpw / (WAVES / split) : p.dpw / WAVES;  // docs per wave / per team (SPLITK: <= SPLIT_MAX_DOCS)
+    const int c_begin = chunk * p.dpw + team * dpwv;
     // (queries past nq - 1 are clamped and not written)
     wg_item(qblk * QB, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
   }

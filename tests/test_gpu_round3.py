@@ -458,3 +458,47 @@ def test_stride_sync_collectives_run_on_rccl(ca, monkeypatch):
     finally:
         monkeypatch.undo()
         dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------------
+# small launches on wide embeddings: docs split over waves (the online call on the default deployment, dim 768)
+# ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype,qdtype,h", [(torch.float16, torch.float32, 768), (torch.float16, torch.float16, 768),
+                                            (torch.bfloat16, torch.float32, 256), (torch.float32, torch.float32, 384)])
+def test_split_small_launch_on_wide_embeddings_is_bit_identical(ca, dtype, qdtype, h):
+    """One query x up to ~1000 ragged docs of up to 384 tokens: each doc streamed by 2 or 4 waves (whole-tile slices, parked
+    per-token maxima, the unsplit wave's floor + sum tree).  Scores equal, bit for bit, those of the batched (unsplit) kernel
+    -- the same candidates scored inside a 64-query batch -- for list lengths that leave teams / workgroups partly filled,
+    docs shorter than a tile (empty slices), empty docs, padding slots, the 0-floor ("negative" query) and q_mask."""
+    gen = torch.Generator().manual_seed(55)
+    ndocs = 700
+    doclens = (torch.randn(ndocs, generator=gen) * 90 + 200).round().clamp(1, 384).long().tolist()
+    doclens[:6] = [384, 1, 31, 32, 33, 0]
+    emb = torch.randn(sum(doclens), h, generator=gen) * 0.1
+    emb[:, 0] += 1.0
+    emb = F.normalize(emb, dim=-1).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=dtype)
+    Qall = nrm(gen, 64, 32, h)
+    Qall[1] = 0.0
+    Qall[1, :, 0] = -1.0                                     # every similarity negative: the 0-floor decides
+    Qall = Qall.to(qdtype)
+    qm = (torch.rand(64, 32, generator=gen) > 0.2).long()
+    qm[:, 0] = 1
+    for n in (1, 2, 3, 4, 5, 9, 333, 1000):
+        cand = torch.randint(0, ndocs, (64, n), generator=gen)
+        cand[:, : min(n, 6)] = torch.arange(min(n, 6))       # the special docs first
+        if n > 8:
+            cand[:, 7] = -1
+        big = r.score_candidates(Qall, cand.cuda()).cpu()                         # 64 queries: the unsplit kernel
+        bigm = r.score_candidates(Qall, cand.cuda(), q_mask=qm).cpu()
+        for qi in (0, 1, 5):
+            one = r.score_candidates(Qall[qi:qi + 1], cand[qi:qi + 1].cuda()).cpu()   # 1 query: the split form
+            assert torch.equal(one[0], big[qi]), (n, qi)
+            onem = r.score_candidates(Qall[qi:qi + 1], cand[qi:qi + 1].cuda(), q_mask=qm[qi:qi + 1]).cpu()
+            assert torch.equal(onem[0], bigm[qi]), (n, qi, "mask")
+    # and through the online call
+    pids = torch.randint(0, ndocs, (500,), generator=gen).tolist()
+    gp, gs = r.rank_forward(Qall[0:1].permute(0, 2, 1), pids, depth=50)
+    c = torch.tensor(pids).view(1, -1).cuda()
+    tp, ts = r.topk(r.score_candidates(Qall[:8], c.expand(8, -1).contiguous())[:1], c, 50)
+    assert gp == tp[0].tolist() and gs == ts[0].tolist()
