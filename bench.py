@@ -314,7 +314,8 @@ def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32
                                    "pmc_source", "mfma_busy_frac", "mfma_tflops")})
     if online_call:     # the reference's online call on this index (its storage dtype): one rank_forward per query
         out["single_query"] = single_query_probe(ranker, Q, cands, h, lq, esize)
-        out["batched_retrieve_step"] = retrieve_step_probe(ranker, Q, dev)
+        if wl["ragged"] is None and h == 128:
+            out["batched_retrieve_step"] = retrieve_step_probe(ranker, Q, dev)
     return out, (idx, doclens)
 
 
@@ -587,7 +588,7 @@ def main():
                                     ("ragged", {}, "ragged fp32 (doclens N(120,40) in 8..180)"),
                                     ("c4", {}, "C4 multi-view: 8 x 8 tokens (BASELINE configs[3])"),
                                     ("c5", {}, "C5 bf16 dim 768, 32 x 256 tokens (BASELINE configs[4])"),
-                                    ("dep768", {}, "reference default deployment: dim 768, fp16 index, doclens N(200,80) in 8..384 "
+                                    ("dep768", dict(online_call=True), "reference default deployment: dim 768, fp16 index, doclens N(200,80) in 8..384 "
                                                    "(proj_conf/dense.yaml:6-8, encoder.py:175)")):
                 o, keep = extra_workload(colbert_amd, name, dev, xs, xw, label=label, **kw)
                 others.append(o)
@@ -669,7 +670,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
             span.append(e0.elapsed_time(e1))
     lat, span = sorted(lat[10:]), sorted(span[10:])
     med, gspan = lat[len(lat) // 2] * 1e3, span[len(span) // 2]
-    ntok = len(pids1) * int(ranker.d_doclens[0].item())
+    ntok = int(ranker.d_doclens[torch.tensor(pids1, device=ranker.device)].sum().item())     # tokens of the last call's candidates
     out.update({"median_ms": round(med, 4), "min_ms": round(lat[0] * 1e3, 4), "gpu_span_ms": round(gspan, 4),
                 "host_ms": round(max(med - gspan, 0.0), 4), "queries_per_s_sequential": round(1e3 / med, 1),
                 "algorithmic_GBps_over_gpu_span": round((ntok * H * esize + LQ * H * 4) / (gspan * 1e-3) / 1e9, 1),
@@ -684,7 +685,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
         e1.synchronize()
         ks.append(e0.elapsed_time(e1) / 20)
     ks = sorted(ks[1:])
-    b16 = 16 * cands.size(2) * int(ranker.d_doclens[0].item()) * H * esize
+    b16 = int(ranker.d_doclens[cands[0, :16].flatten()].sum().item()) * H * esize
     out["batch16"] = {"kernel_ms": round(ks[len(ks) // 2], 4), "algorithmic_GBps": round(b16 / (ks[len(ks) // 2] * 1e-3) / 1e9, 1),
                       "how": "20 launches of 16 queries x 1000 candidates back to back, HIP events around the 20"}
     return out
