@@ -738,11 +738,26 @@ def training_form_probe(dev):
         return e0.elapsed_time(e1) / n
     ms, bms = t(fwd), t(bwd)
     flop = 2.0 * nq * nd * lq * ld * h
+    # yardstick, measured in this run like roofline.read_ceiling: what the vendor GEMM (torch.matmul -> hipBLASLt) reaches
+    # on this box under its power cap -- a large square bf16 GEMM, and the step's own shape (K = 768) on a quarter of the
+    # docs WITH the similarity matrix written out, which the fused kernel never does.  Not on the product path.
+    ga, gb = torch.randn(8192, 8192, device=dev).bfloat16(), torch.randn(8192, 8192, device=dev).bfloat16()
+    gc = torch.empty(8192, 8192, device=dev, dtype=torch.bfloat16)
+    sq_ms = t(lambda: torch.matmul(ga, gb.t(), out=gc), 10)
+    ga = gb = gc = None
+    Q2, D2 = Qt.view(nq * lq, h), Dt.view(nd * ld, h)[: nd * ld // 4]
+    sim = torch.empty(nq * lq, nd * ld // 4, device=dev, dtype=torch.bfloat16)
+    st_ms = t(lambda: torch.matmul(Q2, D2.t(), out=sim), 10)
+    sim = None
+    vendor = {"square_8192_bf16_tflops": round(2.0 * 8192 ** 3 / sq_ms / 1e9, 1),
+              "step_shape_8704x52224x768_tflops": round(flop / 4 / st_ms / 1e9, 1),
+              "what": "torch.matmul (hipBLASLt) in this run, 10 launches between two HIP events; plain GEMMs that write their result"}
     return {"op": "maxsim_score_dense_fwd (scores + arg-max) / maxsim_score_dense_bwd (dQ, dD), Q 272x32x768 x D 544x384x768, bf16, prefix d_mask",
             "kernel": "k_maxsim_allpairs" if _lib.lib.maxsim_score_dense_kernel(nq, nd, lq, ld, h, bf, mf) == 1 else "k_maxsim_stream_bigh",
             "forward_ms": round(ms, 4), "backward_ms": round(bms, 4), "forward_backward_ms": round(ms + bms, 4),
             "tflops": round(flop / ms / 1e9, 1), "peak_tflops_dense_bf16": 2500.0,
-            "frac": round(flop / ms / 1e9 / 2500.0, 4), "how": "20 launches back to back between two HIP events, forward and backward separately",
+            "frac": round(flop / ms / 1e9 / 2500.0, 4), "vendor_gemm": vendor,
+            "frac_of_vendor_square_gemm": round(flop / ms / 1e9 / vendor["square_8192_bf16_tflops"], 4), "how": "20 launches back to back between two HIP events, forward and backward separately",
             "profile": "profiles/r02_allpairs_kernel_stats.csv, profiles/r02_allpairs_pmc.json"}
 
 
