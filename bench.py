@@ -27,6 +27,8 @@ The default N = 1 run also reports, in the same JSON line and each driver-timed 
                   deployment shape (dim 768 fp16 ragged) and the opt-in bf16x3 contraction of the fp32 index
   single_query    the reference's online call (one rank_forward), training_form (the operator's second caller),
   cpu_baseline    the oracle on the host cores (never the product path), roofline.read_ceiling (measured on this box).
+and measures roofline.traffic / mfma_busy_frac itself: three `rocprofv3 --pmc` child runs of the headline workload come
+first, before this process touches the GPU (live_pmc; --no-pmc skips them and replays profiles/).
 """
 import argparse
 import ctypes
@@ -118,6 +120,63 @@ def pmc_lookup(workload, index_dtype, fp32_mode, suffix=""):
         except (OSError, ValueError):
             pass
     return None, None, None
+
+
+PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]))
+
+
+def live_pmc(budget_s=240.0):
+    """The headline kernel's HBM counters measured IN this run: before this process touches the GPU, three short child
+    runs of this same file (headline workload, 1 warm-up + 3 timed launches) under `rocprofv3 --pmc` -- one counter set per
+    pass, no trace domains, as MI355X_MICROARCH.md's HBM section prescribes -- and the per-launch means of their
+    counter_collection.csv: read bytes = 2 * FETCH_SIZE * 1024 (the guide's gfx950 correction for wide coalesced
+    streams), write bytes = WRITE_SIZE * 1024, matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over
+    GRBM_GUI_ACTIVE / 8 XCDs.  Returns (fields, None) or (None, reason): the caller then replays profiles/."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    tmp = tempfile.mkdtemp(prefix="maxsim_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", MAXSIM_BENCH_PMC_CHILD="1")
+    t_end = time.time() + budget_s
+    means, launches = {}, {}
+    try:
+        for name, counters in PMC_PASSES:
+            left = t_end - time.time()
+            if left < 20.0:
+                return None, f"time budget of {budget_s:.0f} s spent before the {name} pass"
+            out = os.path.join(tmp, name)
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
+                                               "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+            try:
+                with open(os.path.join(tmp, name + ".log"), "w") as log:
+                    rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=left).returncode
+            except subprocess.TimeoutExpired:
+                return None, f"{name} pass exceeded the time budget"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if rc != 0 or not files:
+                return None, f"{name} pass: rc {rc}, {len(files)} counter files"
+            vals = {}
+            for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if "k_maxsim" in r["Kernel_Name"]:
+                    vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            for c in counters:
+                if not vals.get(c):
+                    return None, f"{name} pass: no {c} rows for the rerank kernel"
+                means[c], launches[c] = sum(vals[c]) / len(vals[c]), len(vals[c])
+    except OSError as e:
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    rd, wr = 2.0 * means["FETCH_SIZE"] * 1024.0, means["WRITE_SIZE"] * 1024.0
+    return {"traffic": int(rd + wr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
+            "mfma_busy_frac": round((means["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (means["GRBM_GUI_ACTIVE"] / 8.0), 3),
+            "launches_sampled": min(launches.values()),
+            "pmc_source": "live: three `rocprofv3 --pmc` child runs of this command (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
+                          "GRBM_GUI_ACTIVE), run by this bench.py before its own timed region"}, None
 
 
 def timed_steps(step, warmup, steps, barrier=None):
@@ -381,6 +440,8 @@ def main():
                     help="skip everything but the headline measurement (cpu_baseline, single_query, training_form, sharded_share, "
                          "other_workloads, read ceiling): profiling runs")
     ap.add_argument("--no-extras", action="store_true", help="skip sharded_share and other_workloads only")
+    ap.add_argument("--no-pmc", action="store_true",
+                    help="do not run the rocprofv3 --pmc child passes first (roofline.traffic is then replayed from profiles/)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of every sharded_share / other_workloads entry")
     ap.add_argument("--as-rank", type=int, default=-1,
                     help="diagnostic, with --gpus 1: run ONE rank's share of an --of N job on this GPU (256*N queries, candidates "
@@ -400,6 +461,14 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
+
+    # the default run measures its own PMC counters (children first: nothing in this process has touched the GPU yet)
+    pmc_live = pmc_err = None
+    if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("MAXSIM_BENCH_PMC_CHILD") and not args.no_pmc
+            and args.workload == "c2" and not args.no_cpu_baseline and args.as_rank < 0 and not args.force_dist
+            and not (args.ndocs or args.lq or args.nq or args.ncand or args.ld or args.q_dtype or args.index_dtype)
+            and args.fp32_mode == "exact"):
+        pmc_live, pmc_err = live_pmc()
 
     # stdout carries exactly ONE line (the JSON): anything native libraries print there (RCCL's start-up banner) is
     # routed to stderr for the duration of the run
@@ -541,6 +610,13 @@ def main():
     suffix = f"_shard{job_world}" if sim else ""
     rf = roofline_entry(kern_ms, alg_bytes, cand_tokens, LQ, H, args.workload, args.index_dtype, args.fp32_mode,
                         default_shape, suffix)
+
+    if pmc_live is not None and default_shape:
+        rf["traffic_replayed"], rf["pmc_source_replayed"] = rf["traffic"], rf["pmc_source"]
+        rf.update({k: pmc_live[k] for k in ("traffic", "hbm_read_bytes", "hbm_write_bytes", "mfma_busy_frac", "pmc_source")})
+        rf["pmc_launches_sampled"] = pmc_live["launches_sampled"]
+    elif pmc_err is not None:
+        rf["pmc_live_error"] = pmc_err
 
     if rank == 0:
         rag = wl["ragged"]
