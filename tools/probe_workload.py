@@ -8,6 +8,8 @@ import bench, colbert_amd
 dev = torch.device("cuda", 0)
 name = os.environ.get("WL", "ragged")
 wl = dict(bench.WORKLOADS[name])
+if os.environ.get("RAGGED"):          # mean,sd,lo,hi of the clipped normal
+    wl["ragged"] = tuple(int(x) for x in os.environ["RAGGED"].split(","))
 if os.environ.get("UNIFORM"):
     wl["ld"], wl["ragged"] = wl["ragged"][0], None
 dt = os.environ.get("DT", wl["dtype"])
@@ -30,7 +32,7 @@ tok = sum(int(r.d_doclens[cands[i % NB].flatten()].sum()) for i in range(3, 15))
 byts = tok * wl["h"] * idx.element_size()
 a = run(lambda i: r.score_candidates(Q, cands[i % NB]))
 out = "%s %s%s knobs[%s]: static %.4f ms = %.0f GB/s (%.3f of 8 TB/s)" % (
-    name, dt, " uniform" if os.environ.get("UNIFORM") else "", " ".join(f"{k[7:]}={v}" for k, v in os.environ.items() if k.startswith("MAXSIM_") and k != "MAXSIM_LIB"),
+    name, dt, " uniform" if os.environ.get("UNIFORM") else (" N" + os.environ["RAGGED"] if os.environ.get("RAGGED") else ""), " ".join(f"{k[7:]}={v}" for k, v in os.environ.items() if k.startswith("MAXSIM_") and k != "MAXSIM_LIB"),
     a, byts / a / 1e6, byts / a / 1e6 / 8000)
 if wl["h"] == 128 and not os.environ.get("NOLIST"):
     b = run(lambda i: r.score_candidates(Q, cands[i % NB], cand_count=full))
