@@ -1,0 +1,151 @@
+"""GPU: seeded random launches across the dispatch boundaries of the rerank path -- one query to hundreds, one candidate
+to thousands per row, Lq 1..40, narrow and wide embeddings, every index dtype, ragged / uniform / very short docs,
+padding slots, dropped query tokens -- checked three ways:
+  * a sample of (query, slot) entries against the oracle's float64 closed form (oracle/maxsim_oracle.py
+    ragged_scores_f64: the reference's bucket / pad / mask / max / sum, colbert_ranker.py:88-112 + BaseModel.py:41-45,
+    restated per candidate); tolerance as everywhere: fp32 queries |d| <= 1e-4, 16-bit inputs |d| <= 1e-3;
+  * EVERY entry against the same rows scored through the other launch forms, bit for bit: counted rows (the device-built
+    work list), one query per launch (the small / split forms), and the list with its rows permuted;
+  * padding slots are -inf, empty docs 0, and the top-k of a row is the sorted head of its scores.
+The launch forms are chosen by the library from the shape; what this file varies is the shape."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ATOL32 = 1e-4
+ATOL16 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import colbert_amd
+    return colbert_amd
+
+
+def _cases():
+    rng = np.random.RandomState(20261004)
+    out = []
+    for i in range(int(os.environ.get("MAXSIM_FUZZ_CASES", "48"))):     # (more cases: a longer hunt, same seeds first)
+        h = int(rng.choice([128, 128, 128, 128, 768, 768, 256, 384, 64, 96]))
+        dtype = ["fp32", "fp16", "bf16"][int(rng.randint(3))]
+        lq = int(rng.choice([1, 5, 8, 16, 17, 32, 32, 32, 40])) if h == 128 else int(rng.choice([1, 8, 16, 32, 32]))
+        docs = str(rng.choice(["ragged", "ragged", "uniform180", "uniform8", "uniform16", "short", "long", "holes"]))
+        nq, ncand = [(1, 1000), (1, 37), (2, 1000), (5, 300), (64, 1000), (300, 125), (40, 2500), (3, 1)][int(rng.randint(8))]
+        if h >= 256 and docs in ("uniform180", "long", "ragged"):
+            nq, ncand = min(nq, 64), min(ncand, 1000)
+        out.append(dict(i=i, h=h, dtype=dtype, lq=lq, docs=docs, nq=nq, ncand=ncand, q16=bool(rng.rand() < 0.25),
+                        qdrop=str(rng.choice(["none", "none", "len", "mask"])), pad=bool(rng.rand() < 0.5),
+                        mode=str(rng.choice(["exact", "exact", "fast", "bf16x3"]))))
+    return out
+
+
+def _doclens(kind, n, gen):
+    if kind == "ragged":
+        d = (torch.randn(n, generator=gen) * 40 + 120).round().clamp(8, 180)
+    elif kind == "uniform180":
+        d = torch.full((n,), 180.0)
+    elif kind == "uniform8":
+        d = torch.full((n,), 8.0)
+    elif kind == "uniform16":
+        d = torch.full((n,), 16.0)
+    elif kind == "short":
+        d = torch.randint(1, 24, (n,), generator=gen).float()
+    elif kind == "long":
+        d = torch.randint(150, 384, (n,), generator=gen).float()
+    else:  # holes: empty docs between ragged ones
+        d = torch.randint(0, 90, (n,), generator=gen).float()
+        d[::5] = 0
+    d = d.long().tolist()
+    if sum(d) == 0:
+        d[0] = 3
+    return d
+
+
+@pytest.mark.parametrize("c", _cases(), ids=lambda c: f"{c['i']}-h{c['h']}-{c['dtype']}-Lq{c['lq']}-{c['docs']}-{c['nq']}x{c['ncand']}")
+def test_random_launch_shapes(ca, c):
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(7000 + c["i"])
+    h, lq, nq, ncand = c["h"], c["lq"], c["nq"], c["ncand"]
+    tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[c["dtype"]]
+    ndocs = 1500 if h <= 128 else 400
+    doclens = _doclens(c["docs"], ndocs, gen)
+    emb = F.normalize(torch.randn(sum(doclens), h, generator=gen), dim=-1).to(tdt)
+    kw = dict(fp32_mode=c["mode"]) if (tdt == torch.float32 and h == 128) else {}
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=tdt, **kw)
+    q16 = c["q16"] and tdt != torch.float32
+    Q = F.normalize(torch.randn(nq, lq, h, generator=gen), dim=-1)
+    if q16:
+        Q = Q.to(tdt)
+    # rows: live pids first (duplicates allowed, as an ANN list never has them but the interface allows), -1 behind
+    counts = torch.randint(0 if nq > 1 else 1, ncand + 1, (nq,), generator=gen) if c["pad"] else torch.full((nq,), ncand)
+    counts[0] = max(int(counts[0]), 1)
+    cand = torch.full((nq, ncand), -1, dtype=torch.int64)
+    for q in range(nq):
+        k = int(counts[q])
+        cand[q, :k] = torch.randint(0, ndocs, (k,), generator=gen)
+    q_len = q_mask = None
+    live_tok = [list(range(lq)) for _ in range(nq)]
+    if c["qdrop"] == "len":
+        q_len = torch.randint(1, lq + 1, (nq,), generator=gen).int()
+        live_tok = [list(range(int(q_len[q]))) for q in range(nq)]
+    elif c["qdrop"] == "mask":
+        q_mask = (torch.rand(nq, lq, generator=gen) < 0.8).long()
+        q_mask[:, 0] = 1
+        live_tok = [q_mask[q].nonzero().flatten().tolist() for q in range(nq)]
+    dc, dcnt = cand.cuda(), counts.int().cuda()
+    sc = r.score_candidates(Q, dc, q_len=q_len, q_mask=q_mask)
+    got = sc.cpu()
+
+    # ---- the other launch forms, bit for bit ------------------------------------------------------------------
+    counted = r.score_candidates(Q, dc, q_len=q_len, q_mask=q_mask, cand_count=dcnt).cpu()
+    live = torch.arange(ncand)[None, :] < counts[:, None]
+    assert torch.equal(counted[live], got[live])
+    assert bool((counted[~live] == float("-inf")).all()) and bool((got[~live] == float("-inf")).all())
+    for q in sorted(set([0, nq - 1, nq // 2])):            # one query per launch: the small-launch forms
+        one = r.score_candidates(Q[q:q + 1], dc[q:q + 1], q_len=None if q_len is None else q_len[q:q + 1],
+                                 q_mask=None if q_mask is None else q_mask[q:q + 1]).cpu()
+        assert torch.equal(one[0], got[q]), (q, float((one[0] - got[q]).abs().nan_to_num(0, 0, 0).max()))
+    perm = torch.randperm(ncand, generator=gen)
+    shuffled = r.score_candidates(Q, dc[:, perm.cuda()], q_len=q_len, q_mask=q_mask).cpu()
+    assert torch.equal(shuffled, got[:, perm])               # a candidate's score does not depend on its slot
+
+    # ---- a sample of entries against the oracle ---------------------------------------------------------------
+    atol = ATOL16 if (q16 or (tdt == torch.bfloat16 and h != 128)) else ATOL32
+    rows = torch.randint(0, nq, (160,), generator=gen).tolist()
+    pad_len = r.d_pad_len.cpu()
+    checked = 0
+    for q in rows:
+        k = int(counts[q])
+        if k == 0:
+            continue
+        j = int(torch.randint(0, k, (1,), generator=gen))
+        pid = int(cand[q, j])
+        if doclens[pid] == 0:
+            assert got[q, j] == 0.0
+            checked += 1
+            continue
+        Qq = Q[q].float()[live_tok[q]]
+        exp = ragged_scores_f64(emb, r.doclens, r.doclens_pfxsum, pad_len, Qq, [pid])[0]
+        assert abs(float(got[q, j]) - exp) <= atol, (q, j, pid, float(got[q, j]), exp)
+        checked += 1
+    assert checked > 0
+
+    # ---- top-k of the rows ------------------------------------------------------------------------------------
+    k = min(100, ncand)
+    tp, ts = r.topk(sc, dc, k)
+    tpc, tsc = r.topk(sc, dc, k, counts=dcnt)
+    ts, tp, tsc, tpc = ts.cpu(), tp.cpu(), tsc.cpu(), tpc.cpu()
+    exp_s = torch.sort(got, dim=1, descending=True).values[:, :k]
+    assert torch.equal(ts, exp_s)
+    for q in range(nq):
+        n = min(int(counts[q]), k)
+        assert torch.equal(tsc[q, :n], exp_s[q, :n])
+        # every returned (pid, score) pair is a pair of the row
+        pairs = set(zip(cand[q].tolist(), got[q].tolist()))
+        assert all((int(p), float(s)) in pairs for p, s in zip(tpc[q, :n].tolist(), tsc[q, :n].tolist()))
