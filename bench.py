@@ -27,8 +27,9 @@ The default N = 1 run also reports, in the same JSON line and each driver-timed 
                   deployment shape (dim 768 fp16 ragged) and the opt-in bf16x3 contraction of the fp32 index
   single_query    the reference's online call (one rank_forward), training_form (the operator's second caller),
   cpu_baseline    the oracle on the host cores (never the product path), roofline.read_ceiling (measured on this box).
-and measures roofline.traffic / mfma_busy_frac itself: three `rocprofv3 --pmc` child runs of the headline workload come
-first, before this process touches the GPU (live_pmc; --no-pmc skips them and replays profiles/).
+and measures roofline.traffic / mfma_busy_frac itself: three `rocprofv3 --pmc` child runs come first, before this process
+touches the GPU (live_pmc: FETCH_SIZE over the headline and every other_workloads entry, WRITE_SIZE and the MFMA-busy
+counters on the headline; --no-pmc skips them and replays profiles/).
 """
 import argparse
 import ctypes
@@ -123,15 +124,59 @@ def pmc_lookup(workload, index_dtype, fp32_mode, suffix=""):
 
 
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]))
+# the sweep child's workloads, in launch order: (key, workload, extra_workload keywords).  "headline" is the run's own workload.
+PMC_SWEEP = (("headline", "c2", {}), ("c2_bf16x3", "c2", dict(fp32_mode="bf16x3", reuse_prev=True)),
+             ("c2_fp16", "c2", dict(index_dtype="fp16")), ("ragged", "ragged", {}), ("c4", "c4", {}), ("c5", "c5", {}),
+             ("dep768", "dep768", {}))
+PMC_SWEEP_LAUNCHES = 4
 
 
-def live_pmc(budget_s=240.0):
-    """The headline kernel's HBM counters measured IN this run: before this process touches the GPU, three short child
-    runs of this same file (headline workload, 1 warm-up + 3 timed launches) under `rocprofv3 --pmc` -- one counter set per
-    pass, no trace domains, as MI355X_MICROARCH.md's HBM section prescribes -- and the per-launch means of their
-    counter_collection.csv: read bytes = 2 * FETCH_SIZE * 1024 (the guide's gfx950 correction for wide coalesced
-    streams), write bytes = WRITE_SIZE * 1024, matrix pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over
-    GRBM_GUI_ACTIVE / 8 XCDs.  Returns (fields, None) or (None, reason): the caller then replays profiles/."""
+def pmc_sweep_child(manifest_path):
+    """Child of live_pmc's FETCH_SIZE pass: 1 warm-up + 3 rerank launches of the headline workload and of every
+    other_workloads entry, in PMC_SWEEP's order, nothing else from this library on the GPU; what each group of launches
+    should have read (its own algorithmic bytes) goes to the manifest."""
+    import colbert_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    manifest, prev = [], None
+    for key, name, kw in PMC_SWEEP:
+        wl = WORKLOADS[name]
+        lq, ld, h = wl["lq"], wl["ld"], wl["h"]
+        index_dtype = kw.get("index_dtype") or wl["dtype"]
+        dtype = TDT[index_dtype]
+        if kw.get("reuse_prev") and prev is not None:
+            idx, doclens = prev
+        else:
+            prev = idx = None
+            torch.cuda.empty_cache()
+            doclens = make_doclens(wl, wl["ndocs"], ld)
+            idx = build_index(sum(doclens), h, dev, 1234, dtype)
+        ranker = colbert_amd.ColbertRanker.from_device_tensor(idx, doclens, fp32_mode=kw.get("fp32_mode", "exact"))
+        gq = torch.Generator(device=dev).manual_seed(1)
+        Q = F.normalize(torch.randn(NQ, lq, h, generator=gq, device=dev), dim=-1).to(TDT[wl.get("qdtype", "fp32")])
+        gc = torch.Generator(device=dev).manual_seed(2)
+        cands = torch.randint(0, len(doclens), (PMC_SWEEP_LAUNCHES, NQ, NCAND), generator=gc, device=dev, dtype=torch.int64)
+        for i in range(PMC_SWEEP_LAUNCHES):
+            ranker.score_candidates(Q, cands[i])
+        torch.cuda.synchronize()
+        cand_tokens, docs = live_tokens(ranker, cands, 0, len(doclens), 1, PMC_SWEEP_LAUNCHES - 1)
+        manifest.append({"key": key, "launches": PMC_SWEEP_LAUNCHES,
+                         "algorithmic_bytes_per_launch": algorithmic_bytes(cand_tokens, docs, NQ, lq, h, idx.element_size(), Q.element_size())})
+        prev = (idx, doclens)
+        ranker = None
+    with open(manifest_path, "w") as f:
+        json.dump(manifest, f)
+
+
+def live_pmc(budget_s=300.0):
+    """HBM counters measured IN this run: before this process touches the GPU, three short child runs of this same file
+    under `rocprofv3 --pmc` -- one counter set per pass, no trace domains, as MI355X_MICROARCH.md's HBM section prescribes:
+      fetch  FETCH_SIZE over 1 warm-up + 3 rerank launches of the headline workload AND of every other_workloads entry
+             (pmc_sweep_child); read bytes = 2 * FETCH_SIZE * 1024 (the guide's gfx950 correction for wide coalesced streams)
+      write  WRITE_SIZE, headline workload (1 + 3 launches): write bytes = WRITE_SIZE * 1024
+      sq     SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, headline workload
+    Per-launch means over the 3 launches after the warm-up, from the passes' counter_collection.csv.
+    Returns (fields, None) or (None, reason): the caller then replays profiles/."""
     import csv
     import glob
     import shutil
@@ -140,17 +185,18 @@ def live_pmc(budget_s=240.0):
     if exe is None:
         return None, "rocprofv3 not found"
     tmp = tempfile.mkdtemp(prefix="maxsim_pmc_", dir="/tmp")
-    env = dict(os.environ, TMPDIR="/tmp", MAXSIM_BENCH_PMC_CHILD="1")
+    manifest_path = os.path.join(tmp, "sweep.json")
+    env = dict(os.environ, TMPDIR="/tmp", MAXSIM_BENCH_PMC_CHILD="1", MAXSIM_PMC_MANIFEST=manifest_path)
     t_end = time.time() + budget_s
-    means, launches = {}, {}
+    means, sweep = {}, None
     try:
         for name, counters in PMC_PASSES:
             left = t_end - time.time()
             if left < 20.0:
                 return None, f"time budget of {budget_s:.0f} s spent before the {name} pass"
             out = os.path.join(tmp, name)
-            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__),
-                                               "--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+            child = ["--pmc-sweep"] if name == "fetch" else ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+            cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + child
             try:
                 with open(os.path.join(tmp, name + ".log"), "w") as log:
                     rc = subprocess.run(cmd, cwd="/tmp", env=env, stdout=log, stderr=subprocess.STDOUT, timeout=left).returncode
@@ -159,24 +205,34 @@ def live_pmc(budget_s=240.0):
             files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
             if rc != 0 or not files:
                 return None, f"{name} pass: rc {rc}, {len(files)} counter files"
-            vals = {}
-            for r in csv.DictReader(open(max(files, key=os.path.getmtime))):
-                if "k_maxsim" in r["Kernel_Name"]:
-                    vals.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            rows = [r for r in csv.DictReader(open(max(files, key=os.path.getmtime))) if "k_maxsim_stream" in r["Kernel_Name"]]
             for c in counters:
-                if not vals.get(c):
-                    return None, f"{name} pass: no {c} rows for the rerank kernel"
-                means[c], launches[c] = sum(vals[c]) / len(vals[c]), len(vals[c])
-    except OSError as e:
+                seq = [float(r["Counter_Value"]) for r in sorted((r for r in rows if r["Counter_Name"] == c), key=lambda r: int(r["Dispatch_Id"]))]
+                if name == "fetch":
+                    manifest = json.load(open(manifest_path))
+                    if len(seq) != sum(m["launches"] for m in manifest):
+                        return None, f"fetch pass: {len(seq)} rerank launches counted, {sum(m['launches'] for m in manifest)} expected"
+                    sweep, at = {}, 0
+                    for m in manifest:
+                        v = seq[at + 1:at + m["launches"]]          # (the first launch of a group is its warm-up)
+                        at += m["launches"]
+                        rd = 2.0 * (sum(v) / len(v)) * 1024.0
+                        sweep[m["key"]] = {"hbm_read_bytes": int(rd), "launches_sampled": len(v),
+                                           "read_over_algorithmic": round(rd / m["algorithmic_bytes_per_launch"], 4)}
+                else:
+                    if len(seq) < 2:
+                        return None, f"{name} pass: no {c} rows for the rerank kernel"
+                    means[c] = sum(seq[1:]) / len(seq[1:])
+    except (OSError, ValueError, KeyError) as e:
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    rd, wr = 2.0 * means["FETCH_SIZE"] * 1024.0, means["WRITE_SIZE"] * 1024.0
+    rd, wr = float(sweep["headline"]["hbm_read_bytes"]), means["WRITE_SIZE"] * 1024.0
+    src = ("live: `rocprofv3 --pmc` child runs of this file, started by this bench.py before its own timed region (FETCH_SIZE over "
+           "every workload's launches | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE on the headline workload)")
     return {"traffic": int(rd + wr), "hbm_read_bytes": int(rd), "hbm_write_bytes": int(wr),
             "mfma_busy_frac": round((means["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (means["GRBM_GUI_ACTIVE"] / 8.0), 3),
-            "launches_sampled": min(launches.values()),
-            "pmc_source": "live: three `rocprofv3 --pmc` child runs of this command (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES "
-                          "GRBM_GUI_ACTIVE), run by this bench.py before its own timed region"}, None
+            "launches_sampled": sweep["headline"]["launches_sampled"], "pmc_source": src, "sweep": sweep}, None
 
 
 def timed_steps(step, warmup, steps, barrier=None):
@@ -440,6 +496,7 @@ def main():
                     help="skip everything but the headline measurement (cpu_baseline, single_query, training_form, sharded_share, "
                          "other_workloads, read ceiling): profiling runs")
     ap.add_argument("--no-extras", action="store_true", help="skip sharded_share and other_workloads only")
+    ap.add_argument("--pmc-sweep", action="store_true", help=argparse.SUPPRESS)     # live_pmc's FETCH_SIZE child (pmc_sweep_child)
     ap.add_argument("--no-pmc", action="store_true",
                     help="do not run the rocprofv3 --pmc child passes first (roofline.traffic is then replayed from profiles/)")
     ap.add_argument("--extra-steps", type=int, default=10, help="timed steps of every sharded_share / other_workloads entry")
@@ -462,6 +519,9 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.run(cmd).returncode)
 
+    if args.pmc_sweep:
+        pmc_sweep_child(os.environ["MAXSIM_PMC_MANIFEST"])
+        return
     # the default run measures its own PMC counters (children first: nothing in this process has touched the GPU yet)
     pmc_live = pmc_err = None
     if (args.gpus == 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("MAXSIM_BENCH_PMC_CHILD") and not args.no_pmc
@@ -655,24 +715,34 @@ def main():
             # the opt-in 3 x bf16 contraction of the SAME fp32 index (fp32-class accuracy, not an exact fmaf chain: labelled extra)
             o, keep = extra_workload(colbert_amd, "c2", dev, xs, xw, fp32_mode="bf16x3", reuse=(idx, doclens), online_call="only", label="c2 fp32 index, fp32_mode=bf16x3 (opt-in)")
             o["accuracy"] = "fp32-class (tests/test_gpu_parity.py::test_fp32_bf16x3_mode_is_fp32_accurate); default stays the exact fmaf chain"
+            o["pmc_key"] = "c2_bf16x3"
             others.append(o)
             # the 92 GB headline index leaves HBM before the next ones are built (every name that reaches it is cleared:
             # the closures above share these cells)
             ranker = sharded = idx = cands = score_inner = keep = None
             torch.cuda.empty_cache()
-            for name, kw, label in (("c2", dict(index_dtype="fp16", online_call=True), "c2 with the reference's fp16 index (colbert_ranker.py:62)"),
-                                    ("ragged", {}, "ragged fp32 (doclens N(120,40) in 8..180)"),
-                                    ("c4", {}, "C4 multi-view: 8 x 8 tokens (BASELINE configs[3])"),
-                                    ("c5", {}, "C5 bf16 dim 768, 32 x 256 tokens (BASELINE configs[4])"),
-                                    ("dep768", dict(online_call=True), "reference default deployment: dim 768, fp16 index, doclens N(200,80) in 8..384 "
-                                                   "(proj_conf/dense.yaml:6-8, encoder.py:175)")):
+            for key, name, kw, label in (("c2_fp16", "c2", dict(index_dtype="fp16", online_call=True), "c2 with the reference's fp16 index (colbert_ranker.py:62)"),
+                                         ("ragged", "ragged", {}, "ragged fp32 (doclens N(120,40) in 8..180)"),
+                                         ("c4", "c4", {}, "C4 multi-view: 8 x 8 tokens (BASELINE configs[3])"),
+                                         ("c5", "c5", {}, "C5 bf16 dim 768, 32 x 256 tokens (BASELINE configs[4])"),
+                                         ("dep768", "dep768", dict(online_call=True), "reference default deployment: dim 768, fp16 index, doclens N(200,80) in 8..384 "
+                                                              "(proj_conf/dense.yaml:6-8, encoder.py:175)")):
                 o, keep = extra_workload(colbert_amd, name, dev, xs, xw, label=label, **kw)
+                o["pmc_key"] = key
                 others.append(o)
                 keep = None
                 torch.cuda.empty_cache()
             if "read_ceiling" in rf:
                 for o in others:
                     o["frac_of_read_ceiling"] = round(o["achieved"] / rf["read_ceiling"]["GBps"], 4)
+            for o in others:       # this run's own FETCH_SIZE pass over the workload's launches (live_pmc), where there is one
+                live = (pmc_live or {}).get("sweep", {}).get(o.pop("pmc_key"))
+                if live is not None:
+                    o["traffic_replayed"], o["pmc_source_replayed"] = o["traffic"], o["pmc_source"]
+                    o["traffic"] = live["hbm_read_bytes"]
+                    o["read_over_algorithmic"] = live["read_over_algorithmic"]
+                    o["pmc_source"] = ("live: FETCH_SIZE pass of this run over 3 launches of this workload (reads only; the writes are "
+                                       "its score matrix, 1 MB; mfma_busy_frac stays the replayed value)")
             res["other_workloads"] = others
         if full:
             res["training_form"] = training_form_probe(dev)
