@@ -80,6 +80,29 @@ inline int pick_docs_per_wave(const Params& p, int waves) {
   return dpwv;
 }
 
+// Mid-size launches: a static grid a little larger than a whole number of rounds of the kernel's resident workgroup
+// slots (`slots` = workgroups the chip holds at once: 256 CUs x workgroups per CU) ends with a nearly empty round --
+// 16 queries x 1000 docs at dim 768: 288 workgroups on 256 slots, the last 32 alone for as long as the first 256 took.
+// A workgroup's duration is its own serial stream, ~ proportional to its docs: among the docs-per-wave values between half
+// and twice the stream-length rule's choice, take the one with the smallest rounds x docs when that saves >= 10 %.
+// Scores do not depend on the cut (bit-identical); large launches (>= 4 rounds) are left alone.
+inline int refine_docs_per_wave(const Params& p, int dpwv, int waves, int slots) {
+  auto rounds = [&](int d) {
+    const int64_t wgs = (int64_t)p.nq * ((p.ncand + (int64_t)d * waves - 1) / ((int64_t)d * waves));
+    return (wgs + slots - 1) / slots;
+  };
+  const int64_t r0 = rounds(dpwv);
+  if (r0 < 2 || r0 > 4 || MAXSIM_KNOB("MAXSIM_NO_REFINE", 0)) return dpwv;
+  int best = dpwv;
+  int64_t best_cost = r0 * dpwv;
+  const int hi = dpwv * 2 < 64 ? dpwv * 2 : 64, lo = dpwv / 2 > 1 ? dpwv / 2 : 1;
+  for (int d = hi; d >= lo; --d) {
+    const int64_t c = rounds(d) * d;
+    if (c < best_cost) { best_cost = c; best = d; }
+  }
+  return best_cost * 10 <= r0 * dpwv * 9 ? best : dpwv;
+}
+
 // tu_stream.hip: the h = 128 register-query kernel.  index_dtype: MAXSIM_F32 / F16 / BF16 / F32_FAST / F32_BF16X3.
 int launch_stream_rerank(Params& p, int index_dtype, hipStream_t st);
 int launch_stream_dense_f32(Params& p, hipStream_t st);

@@ -16,8 +16,11 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
   const int avail = 160 * 1024 - qbytes;
   int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);
   if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4);
+  const bool knob_dpw = MAXSIM_KNOB("MAXSIM_DPW", 0) > 0;
   auto go = [&](auto kern, int waves, int nt) {
-    p.dpw = dpwv * waves;
+    // (workgroups resident at once: one per CU above 80 KiB of LDS, else two)
+    const int dw = (MODE == MODE_RERANK && !knob_dpw) ? refine_docs_per_wave(p, dpwv, waves, qbytes + waves * nt * SUB > 80 * 1024 ? 256 : 512) : dpwv;
+    p.dpw = dw * waves;
     p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
     const int ldsb = qbytes + waves * nt * SUB;
     int rc = allow_lds(kern, ldsb);

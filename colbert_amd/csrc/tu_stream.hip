@@ -8,7 +8,10 @@ namespace {
 template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32>
 int launch_stream_v(Params& p, hipStream_t st) {
   int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);  // tuning knob (diagnostic builds): docs per wave
-  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
+  if (dpwv <= 0 || dpwv > 64) {
+    dpwv = pick_docs_per_wave(p, WAVES);
+    if (MODE == MODE_RERANK) dpwv = refine_docs_per_wave(p, dpwv, WAVES, WAVES * NT * StreamTraits<DT>::TILE > 80 * 1024 ? 256 : 512);
+  }
   p.dpw = dpwv * WAVES;
   p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
   const int ldsb = WAVES * NT * StreamTraits<DT>::TILE;
