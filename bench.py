@@ -528,7 +528,10 @@ def main():
             and args.workload == "c2" and not args.no_cpu_baseline and args.as_rank < 0 and not args.force_dist
             and not (args.ndocs or args.lq or args.nq or args.ncand or args.ld or args.q_dtype or args.index_dtype)
             and args.fp32_mode == "exact"):
-        pmc_live, pmc_err = live_pmc()
+        try:
+            pmc_live, pmc_err = live_pmc()
+        except Exception as e:      # whatever happens in the profiler passes, the bench line itself must still be produced
+            pmc_live, pmc_err = None, f"{type(e).__name__}: {e}"
 
     # stdout carries exactly ONE line (the JSON): anything native libraries print there (RCCL's start-up banner) is
     # routed to stderr for the duration of the run
