@@ -184,6 +184,8 @@ def live_pmc(budget_s=300.0):
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
+    if any("rocprof" in v.lower() for k, v in os.environ.items() if k in ("LD_PRELOAD", "HSA_TOOLS_LIB", "ROCP_TOOL_LIBRARIES")):
+        return None, "this process is itself running under a profiler: no nested passes"
     tmp = tempfile.mkdtemp(prefix="maxsim_pmc_", dir="/tmp")
     manifest_path = os.path.join(tmp, "sweep.json")
     env = dict(os.environ, TMPDIR="/tmp", MAXSIM_BENCH_PMC_CHILD="1", MAXSIM_PMC_MANIFEST=manifest_path)
