@@ -167,6 +167,38 @@ def main():
          expected_scores=all_scores, expected_scores_neg=all_scores_neg,
          top10_pids=np.array(top_p), top10_scores=np.array(top_s, dtype=np.float64))
 
+    # (9) the batched driver's masked-token compaction: the reference drops a query's masked tokens with
+    #     training_utils.keep_nonzero before search() (dense_server_client.py:45 via qd_mask_to_realinput(keep_dim=False),
+    #     training_utils.py:48-53,84-93) -- both imported here -- and scores what is left.  Holes in the middle of the
+    #     sequence (the tokenizer zeroes punctuation and [SEP]), a ragged rerank behind it: 12 docs of 1..40 tokens, fp16
+    #     index, three queries with different masks (one with a single live token).
+    from colbert.training.training_utils import keep_nonzero as REF_KEEP, qd_mask_to_realinput as REF_REALINPUT
+    from oracle.maxsim_oracle import keep_nonzero as my_keep
+    g = torch.Generator().manual_seed(9)
+    ndocs, dim, Lq = 12, 128, 32
+    doclens = torch.randint(1, 41, (ndocs,), generator=g).tolist()
+    parts_doclens = [doclens[:5], doclens[5:]]
+    parts = [norm_randn(g, sum(dl), dim).half() for dl in parts_doclens]
+    ranker = RefRanker(parts, parts_doclens, dim=dim, score_fn=REF)
+    Qs = norm_randn(g, 3, Lq, dim)
+    masks = (torch.rand(3, Lq, generator=g) < 0.7).long()
+    masks[:, 0] = 1
+    masks[1, 20:] = 0                      # a padded tail as well
+    masks[2] = 0
+    masks[2, 5] = 1                        # one live token, not the first
+    pids = torch.randperm(ndocs, generator=g).tolist()
+    exp = []
+    for q in range(3):
+        real_q, real_m = REF_REALINPUT(t=Qs[q], t_mask=masks[q], max_length=Lq, keep_dim=False)
+        rq2, rm2 = REF_KEEP(Qs[q], masks[q])
+        mq, mm = my_keep(Qs[q], masks[q])
+        assert torch.equal(real_q, rq2) and torch.equal(real_q, mq) and torch.equal(real_m, mm), "oracle keep_nonzero != reference"
+        assert real_q.size(0) == int(masks[q].sum())
+        exp.append(ranker.all_scores(real_q.unsqueeze(0).permute(0, 2, 1).contiguous(), pids))    # faiss_indexers.py:232-234
+    save("masked_query_rerank", part0=parts[0], part1=parts[1], doclens0=np.array(parts_doclens[0]),
+         doclens1=np.array(parts_doclens[1]), Q=Qs, q_word_mask=masks, pids=np.array(pids),
+         expected_scores=torch.stack(exp))
+
     # dtype propagation facts: fp32*int64 -> fp32 ; fp16*int64 -> fp16
     a = REF(torch.ones(1, 2, 4), torch.ones(1, 2, 4), torch.ones(1, 2, dtype=torch.long), torch.ones(1, 2, dtype=torch.long))
     assert a.dtype == torch.float32

@@ -296,6 +296,34 @@ def test_ragged_768_fp16_batch_vs_oracle(ca):
         np.testing.assert_allclose(sc16[qi].numpy(), exp, rtol=0, atol=ATOL16)
 
 
+def test_masked_query_rerank_golden(ca, golden):
+    """The batched driver's q_mask / q_len predicates against the fixture the imported reference wrote by compacting the
+    query first (keep_nonzero, training_utils.py:48-53) and scoring what is left: one launch for the three queries with
+    their masks, the compacted queries one by one, and retrieve-style counted rows -- fp16 index as the reference stores it."""
+    g = golden("masked_query_rerank")
+    r = ca.ColbertRanker(parts=[g["part0"], g["part1"]], parts_doclens=[g["doclens0"].tolist(), g["doclens1"].tolist()],
+                         dim=128, index_dtype=torch.float16)
+    pids = g["pids"].cuda()
+    cand = pids[None, :].repeat(3, 1)
+    exp = g["expected_scores"]
+    sc = r.score_candidates(g["Q"], cand, q_mask=g["q_word_mask"]).cpu()
+    torch.testing.assert_close(sc, exp, rtol=0, atol=ATOL32)
+    cnt = torch.full((3,), cand.size(1), dtype=torch.int32, device="cuda")
+    sc2 = r.score_candidates(g["Q"], cand, q_mask=g["q_word_mask"], cand_count=cnt).cpu()
+    assert torch.equal(sc2, sc)
+    for q in range(3):                                   # the reference's own order of operations: compact, then score
+        live = g["q_word_mask"][q].bool()
+        one = r.score_candidates(g["Q"][q][live][None], cand[q:q + 1]).cpu()
+        torch.testing.assert_close(one[0], exp[q], rtol=0, atol=ATOL32)
+        tp, ts = r.rank_forward(g["Q"][q][live][None].permute(0, 2, 1), g["pids"].tolist(), depth=5)
+        order = torch.argsort(exp[q], descending=True)[:5]
+        np.testing.assert_allclose(ts, exp[q][order].numpy(), rtol=0, atol=ATOL32)
+    # query 1's mask is a prefix mask plus holes: q_len alone (the prefix form) must NOT equal it, q_len + q_mask must
+    ql = torch.tensor([32, 20, 32], dtype=torch.int32)
+    sc3 = r.score_candidates(g["Q"], cand, q_len=ql, q_mask=g["q_word_mask"]).cpu()
+    torch.testing.assert_close(sc3, exp, rtol=0, atol=ATOL32)
+
+
 # ------------------------------------------------------------------------------------------------------
 # the online call (maxsim_rank_forward: rerank + counting top-k, polled completion) against the batched entry points
 # ------------------------------------------------------------------------------------------------------

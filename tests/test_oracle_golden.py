@@ -89,6 +89,25 @@ def test_ragged_rerank_768_golden(golden):
     assert floored.any() and (~floored).any()
 
 
+def test_masked_query_rerank_golden(golden):
+    """Masked-token compaction before the rerank (training_utils.py:48-53 via dense_server_client.py:45): the oracle's
+    keep_nonzero + RefRanker against the fixture written by the IMPORTED keep_nonzero / qd_mask_to_realinput / score
+    (make_golden.py section 9): mid-sequence holes, a padded tail, a query with one live token."""
+    from oracle.maxsim_oracle import keep_nonzero
+    g = golden("masked_query_rerank")
+    r = RefRanker([g["part0"], g["part1"]], [g["doclens0"].tolist(), g["doclens1"].tolist()], dim=128)
+    pids = g["pids"].tolist()
+    pad_len = r.bucket_strides(list(range(len(r.doclens))))
+    for q in range(3):
+        real_q, real_m = keep_nonzero(g["Q"][q], g["q_word_mask"][q])
+        assert real_q.size(0) == int(g["q_word_mask"][q].sum()) and bool((real_m == 1).all())
+        got = r.all_scores(real_q.unsqueeze(0).permute(0, 2, 1).contiguous(), pids)
+        torch.testing.assert_close(got, g["expected_scores"][q], rtol=0, atol=1e-5)
+        f64 = ragged_scores_f64(r.tensor, r.doclens, r.doclens_pfxsum, pad_len, real_q, pids)
+        np.testing.assert_allclose(g["expected_scores"][q].numpy(), f64, rtol=0, atol=3e-5)
+    assert int(g["q_word_mask"][2].sum()) == 1
+
+
 def test_ragged_closed_form_equals_bucketed(golden):
     """The fused kernel's definition (real tokens + analytic 0-floor) equals the reference's bucket/pad/mask."""
     g = golden("ragged_rerank_64")
