@@ -1,6 +1,8 @@
 """CPU, world_size 2, gloo: the training-form all-gather glue (colbert_amd/training.py <- training_utils.py:22-45,
 colbert_model.py:87-90).  Values and gradients of every rank against ONE process that holds the whole batch and the
-oracle's score(); the scorer injected on the CPU ranks is the oracle (the HIP operator's own autograd is a GPU test)."""
+oracle's score(), and against the fixture the IMPORTED reference glue + score wrote in the same two-rank job
+(tests/golden/make_golden_gather.py); the scorer injected on the CPU ranks is the oracle (the HIP operator's own
+autograd is a GPU test)."""
 import os
 import socket
 
@@ -67,6 +69,16 @@ def _worker(rank, world, port, ret):
         checks["dQ"] = torch.allclose(Q.grad, Qw.grad[rank * B:(rank + 1) * B], atol=1e-5, rtol=1e-4)
         checks["dD"] = torch.allclose(D.grad, Dw.grad[rank * 2 * B:(rank + 1) * 2 * B], atol=1e-5, rtol=1e-4)
         checks["grad_nonzero"] = float(Q.grad.abs().sum()) > 0 and float(D.grad.abs().sum()) > 0
+        # ... and against what the IMPORTED reference glue + score produced in the same two-rank job
+        # (tests/golden/make_golden_gather.py -> training_gather_world2.npz)
+        import numpy as np
+        gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "training_gather_world2.npz"))
+        gr = {k[len(f"rank{rank}_"):]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith(f"rank{rank}_")}
+        checks["golden_gathered"] = torch.equal(Qa.detach(), gr["Qa"]) and torch.equal(Da.detach(), gr["Da"]) and \
+            torch.equal(qma, gr["qma"]) and torch.equal(dma, gr["dma"])
+        checks["golden_scores"] = torch.allclose(scores.detach(), gr["scores"], atol=1e-6, rtol=0)
+        checks["golden_grads"] = torch.allclose(Q.grad, gr["dQ"], atol=1e-5, rtol=1e-4) and \
+            torch.allclose(D.grad, gr["dD"], atol=1e-5, rtol=1e-4)
         parts = distributed_concat(qm, concat=False)
         checks["concat_false"] = len(parts) == world and all(torch.equal(parts[r], allb[r][2]) for r in range(world))
         checks["truncate"] = distributed_concat(qm, num_total_examples=4).size(0) == 4
