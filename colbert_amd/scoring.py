@@ -21,6 +21,11 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
+def _has_weights(mask):
+    """True when a floating-point mask holds anything but 0 and 1 (one small reduction; integer / bool masks never ask)."""
+    return bool(((mask != 0) & (mask != 1)).any().item())
+
+
 def _prepare(Q, D, q_mask, d_mask):
     if Q.dim() != 3 or D.dim() != 3 or q_mask.dim() != 2 or d_mask.dim() != 2:
         raise ValueError("score expects Q[q,m,h], D[d,n,h], q_mask[q,m], d_mask[d,n]")
@@ -34,6 +39,11 @@ def _prepare(Q, D, q_mask, d_mask):
     dev = Q.device
     out_dtype = torch.promote_types(torch.promote_types(Q.dtype, q_mask.dtype), torch.promote_types(D.dtype, d_mask.dtype))
     cdt = Q.dtype if Q.dtype == D.dtype and Q.dtype in _DT else torch.float32
+    if cdt != torch.float32 and q_mask.dtype.is_floating_point and _has_weights(q_mask):
+        # a floating-point q_mask that is not 0/1 (token WEIGHTS: allowed by the interface, never built by the reference,
+        # tokenizers.py:36,57): the 16-bit kernels fold Q * q_mask into a 16-bit query image, where the reference's product is
+        # exact in the promoted type (BaseModel.py:42) -- up to 3e-3 on a bf16 score.  Such calls compute from fp32 copies.
+        cdt = torch.float32
     Qc = Q.detach().to(device=dev, dtype=cdt).contiguous()
     Dc = D.detach().to(device=dev, dtype=cdt).contiguous()
     mdt = d_mask.dtype if d_mask.dtype in _MDT else torch.float32
@@ -86,11 +96,29 @@ class _MaxSimFn(torch.autograd.Function):
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             else:
                 ws_bytes = 0
+        HMAX = 1024                               # widest row the backward kernels take (maxsim_backward.h)
         with torch.cuda.device(dev):
-            rc = _lib.lib.maxsim_score_dense_bwd(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), _ptr(arg), _ptr(g32), nq, nd, Lq,
-                                                 Ld, h, _DT[cdt], _MDT[mdt], _ptr(dQ), _ptr(dD), _ptr(ws), ws_bytes,
-                                                 _stream(dev))
-        _lib.check(rc, "maxsim_score_dense_bwd")
+            if h <= HMAX:
+                rc = _lib.lib.maxsim_score_dense_bwd(_ptr(Qc), _ptr(Dc), _ptr(qm), _ptr(dm), _ptr(arg), _ptr(g32), nq, nd, Lq,
+                                                     Ld, h, _DT[cdt], _MDT[mdt], _ptr(dQ), _ptr(dD), _ptr(ws), ws_bytes,
+                                                     _stream(dev))
+                _lib.check(rc, "maxsim_score_dense_bwd")
+            else:
+                # both gradients are sums of ROWS picked by the arg-max (dQ[q,m,:] = sum_d g D[d, arg, :], dD likewise):
+                # they separate along the hidden dimension, so wider rows go through the same kernels in slabs of columns
+                for h0 in range(0, h, HMAX):
+                    h1 = min(h0 + HMAX, h)
+                    Qs, Ds = Qc[..., h0:h1].contiguous(), Dc[..., h0:h1].contiguous()
+                    dQs = None if dQ is None else torch.empty(nq, Lq, h1 - h0, dtype=torch.float32, device=dev)
+                    dDs = None if dD is None else torch.empty(nd, Ld, h1 - h0, dtype=torch.float32, device=dev)
+                    rc = _lib.lib.maxsim_score_dense_bwd(_ptr(Qs), _ptr(Ds), _ptr(qm), _ptr(dm), _ptr(arg), _ptr(g32), nq, nd,
+                                                         Lq, Ld, h1 - h0, _DT[cdt], _MDT[mdt], _ptr(dQs), _ptr(dDs), _ptr(ws),
+                                                         ws_bytes, _stream(dev))
+                    _lib.check(rc, "maxsim_score_dense_bwd")
+                    if dQ is not None:
+                        dQ[..., h0:h1] = dQs
+                    if dD is not None:
+                        dD[..., h0:h1] = dDs
         return (None if dQ is None else dQ.to(qdt)), (None if dD is None else dD.to(ddt)), None, None
 
 

@@ -149,3 +149,82 @@ def test_random_launch_shapes(ca, c):
         # every returned (pid, score) pair is a pair of the row
         pairs = set(zip(cand[q].tolist(), got[q].tolist()))
         assert all((int(p), float(s)) in pairs for p, s in zip(tpc[q, :n].tolist(), tsc[q, :n].tolist()))
+
+
+# ------------------------------------------------------------------------------------------------------
+# the operator itself: BaseModel.score (BaseModel.py:39-46), all-pairs, with masks, under random shapes / dtypes
+# ------------------------------------------------------------------------------------------------------
+def _dense_cases():
+    rng = np.random.RandomState(4242)
+    out = []
+    for i in range(int(os.environ.get("MAXSIM_FUZZ_CASES", "48"))):
+        h = int(rng.choice([1, 3, 16, 24, 64, 96, 128, 128, 200, 256, 384, 768, 1024, 1100]))
+        out.append(dict(i=i, h=h, nq=int(rng.choice([1, 2, 3, 7, 33])), nd=int(rng.choice([1, 2, 5, 19, 64])),
+                        lq=int(rng.choice([1, 2, 8, 16, 31, 32, 33, 40, 64])), ld=int(rng.choice([1, 2, 7, 8, 31, 32, 33, 100, 180, 257, 384])),
+                        dtype=str(rng.choice(["fp32", "fp32", "fp16", "bf16"])),
+                        mask=str(rng.choice(["int64", "float32", "bool", "int32", "float16", "weights"])),
+                        grad=bool(rng.rand() < 0.3)))
+    return out
+
+
+@pytest.mark.parametrize("c", _dense_cases(), ids=lambda c: f"{c['i']}-{c['nq']}x{c['nd']}-{c['lq']}x{c['ld']}-h{c['h']}-{c['dtype']}-{c['mask']}{'-grad' if c['grad'] else ''}")
+def test_random_dense_score(ca, c):
+    """ca.score against the oracle's four torch ops (oracle.maxsim_oracle.ref_score == the imported BaseModel.score,
+    tests/golden/make_golden.py) on the same tensors: result dtype as torch promotes it, values within the stated
+    tolerance (fp32 operands 1e-4; 16-bit operands: the oracle evaluated in fp32 on the rounded operands, 1e-3 + the
+    result's own 16-bit rounding), and -- where asked -- gradients against torch autograd through the oracle."""
+    from oracle.maxsim_oracle import ref_score
+    gen = torch.Generator().manual_seed(9000 + c["i"])
+    tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[c["dtype"]]
+    nq, nd, lq, ld, h = c["nq"], c["nd"], c["lq"], c["ld"], c["h"]
+    Q = F.normalize(torch.randn(nq, lq, h, generator=gen), dim=-1).to(tdt)
+    D = F.normalize(torch.randn(nd, ld, h, generator=gen), dim=-1).to(tdt)
+    if c["mask"] == "weights":                       # arbitrary non-negative float weights, not only 0/1
+        qm, dm = torch.rand(nq, lq, generator=gen), torch.rand(nd, ld, generator=gen)
+    else:
+        mdt = {"int64": torch.int64, "float32": torch.float32, "bool": torch.bool, "int32": torch.int32, "float16": torch.float16}[c["mask"]]
+        qm = (torch.rand(nq, lq, generator=gen) > 0.2).to(mdt)
+        dm = (torch.rand(nd, ld, generator=gen) > 0.3).to(mdt)
+    exp32 = ref_score(Q.float(), D.float(), qm.float(), dm.float())
+    exp_dtype = (Q[:1, :1, :1] * qm[:1, :1, None]).dtype          # BaseModel.py:41-42: the promoted type of operand * mask
+    use_grad = c["grad"] and tdt == torch.float32 and c["mask"] != "weights"
+    Qg, Dg = Q.cuda(), D.cuda()
+    if use_grad:
+        Qg.requires_grad_(True)
+        Dg.requires_grad_(True)
+    out = ca.score(Qg, Dg, qm.cuda(), dm.cuda())
+    assert tuple(out.shape) == (nq, nd)
+    assert out.dtype == exp_dtype, (out.dtype, exp_dtype)
+    if tdt == torch.float32 and exp_dtype == torch.float32:
+        atol = ATOL32
+    else:
+        atol = ATOL16 + float(exp32.abs().max()) * (2.0 ** -8 if exp_dtype == torch.bfloat16 else 2.0 ** -11 if exp_dtype == torch.float16 else 0.0)
+    torch.testing.assert_close(out.detach().float().cpu(), exp32, rtol=0, atol=atol)
+    if use_grad:
+        Qr, Dr = Q.clone().requires_grad_(True), D.clone().requires_grad_(True)
+        w = torch.randn(nq, nd, generator=gen)
+        (ref_score(Qr, Dr, qm, dm) * w).sum().backward()
+        (out * w.cuda()).sum().backward()
+        torch.testing.assert_close(Qg.grad.cpu(), Qr.grad, rtol=1e-4, atol=1e-5)
+        torch.testing.assert_close(Dg.grad.cpu(), Dr.grad, rtol=1e-4, atol=1e-5)
+
+
+def test_backward_on_rows_wider_than_the_backward_kernels(ca):
+    """h > 1024 (found by the sweep above at 600 cases): the backward kernels take rows up to 1024 wide; wider rows go
+    through them in slabs of columns (colbert_amd/scoring.py) -- gradients against torch autograd through the oracle."""
+    from oracle.maxsim_oracle import ref_score
+    gen = torch.Generator().manual_seed(104)
+    Q = F.normalize(torch.randn(2, 5, 1100, generator=gen), dim=-1)
+    D = F.normalize(torch.randn(3, 40, 1100, generator=gen), dim=-1)
+    qm = (torch.rand(2, 5, generator=gen) > 0.2).long()
+    dm = (torch.rand(3, 40, generator=gen) > 0.3).long()
+    Qg, Dg = Q.cuda().requires_grad_(True), D.cuda().requires_grad_(True)
+    Qr, Dr = Q.clone().requires_grad_(True), D.clone().requires_grad_(True)
+    w = torch.randn(2, 3, generator=gen)
+    out = ca.score(Qg, Dg, qm.cuda(), dm.cuda())
+    exp = ref_score(Qr, Dr, qm, dm)
+    torch.testing.assert_close(out.detach().cpu(), exp.detach(), rtol=0, atol=ATOL32)
+    (out * w.cuda()).sum().backward()
+    (exp * w).sum().backward()
+    torch.testing.assert_close(Qg.grad.cpu(), Qr.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(Dg.grad.cpu(), Dr.grad, rtol=1e-4, atol=1e-5)
