@@ -228,3 +228,113 @@ def test_backward_on_rows_wider_than_the_backward_kernels(ca):
     (exp * w).sum().backward()
     torch.testing.assert_close(Qg.grad.cpu(), Qr.grad, rtol=1e-4, atol=1e-5)
     torch.testing.assert_close(Dg.grad.cpu(), Dr.grad, rtol=1e-4, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------------
+# doc-sharded rerank on one GPU: N shards scored one after the other, merged, against ONE whole-index ranker
+# ------------------------------------------------------------------------------------------------------
+def _shard_cases():
+    rng = np.random.RandomState(777)
+    return [dict(i=i, world=int(rng.choice([2, 3, 5, 8])), nq=int(rng.choice([1, 3, 9, 40])), ncand=int(rng.choice([1, 17, 100, 400])),
+                 k=int(rng.choice([1, 10, 100])), dtype=str(rng.choice(["fp32", "fp16"])), docs=str(rng.choice(["ragged", "short", "uniform8"])),
+                 skew=bool(rng.rand() < 0.4), qdrop=bool(rng.rand() < 0.3))
+            for i in range(max(8, int(os.environ.get("MAXSIM_FUZZ_CASES", "48")) // 3))]
+
+
+@pytest.mark.parametrize("c", _shard_cases(), ids=lambda c: f"{c['i']}-w{c['world']}-{c['nq']}x{c['ncand']}-k{c['k']}-{c['dtype']}-{c['docs']}{'-skew' if c['skew'] else ''}")
+def test_random_sharded_rerank(ca, c):
+    """Pid-range shards bucketed by the strides of the WHOLE index, global candidate lists handed to every shard, local
+    top-k with global pids, merge: the merged (pid, score) lists against one unsharded ranker over the same docs -- the same
+    kernels, so the scores are the same bits; ranks that hold none of a query's candidates contribute padding."""
+    from colbert_amd.ranker import reference_strides
+    from colbert_amd.sharded import ShardedRanker, merge_gathered, shard_range
+    gen = torch.Generator().manual_seed(5000 + c["i"])
+    world, nq, ncand, k = c["world"], c["nq"], c["ncand"], c["k"]
+    tdt = torch.float32 if c["dtype"] == "fp32" else torch.float16
+    ndocs, h = 900, 128
+    doclens = _doclens(c["docs"], ndocs, gen)
+    emb = F.normalize(torch.randn(sum(doclens), h, generator=gen), dim=-1).to(tdt)
+    whole = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=tdt)
+    Q = F.normalize(torch.randn(nq, 32, h, generator=gen), dim=-1)
+    hi_pid = ndocs // world if c["skew"] else ndocs            # skew: every candidate lives on the first shard
+    cand = torch.stack([torch.randperm(hi_pid, generator=gen)[:ncand] if ncand <= hi_pid else torch.randint(0, hi_pid, (ncand,), generator=gen)
+                        for _ in range(nq)])
+    q_len = torch.randint(1, 33, (nq,), generator=gen).int() if c["qdrop"] else None
+    kk = min(k, ncand)
+    ref_scores = whole.score_candidates(Q, cand.cuda(), q_len=q_len)
+    exp_s = torch.sort(ref_scores.cpu(), dim=1, descending=True).values[:, :kk]
+    offs = np.concatenate([[0], np.cumsum(doclens)])
+    gstr = reference_strides(torch.tensor(doclens))
+    tops = []
+    for rank in range(world):
+        lo, hi = shard_range(ndocs, rank, world)
+        r = ca.ColbertRanker(parts=[emb[offs[lo]:offs[hi]]], parts_doclens=[doclens[lo:hi]], dim=h, index_dtype=tdt, strides=gstr)
+        tops.append(ShardedRanker(r, lo, hi, sync_strides=False).local_topk(Q, cand.cuda(), kk, q_len=q_len))
+    gs, gp = torch.stack([t[1] for t in tops]), torch.stack([t[0] for t in tops])
+    mp, ms = merge_gathered(gs, gp, kk, whole.topk)
+    assert torch.equal(ms.cpu(), exp_s)                         # the same bits as the unsharded ranker
+    look = [dict(zip(cand[q].tolist(), ref_scores[q].cpu().tolist())) for q in range(nq)]
+    for q in range(nq):
+        got = mp[q].cpu().tolist()
+        assert len(set(got)) == len(got) or ncand > hi_pid       # distinct candidates stay distinct
+        assert all(look[q][p] == s for p, s in zip(got, ms[q].cpu().tolist()))
+
+
+# ------------------------------------------------------------------------------------------------------
+# the online call, as the reference's caller makes it and in the other forms its signature admits
+# ------------------------------------------------------------------------------------------------------
+def _rf_cases():
+    rng = np.random.RandomState(31337)
+    return [dict(i=i, h=int(rng.choice([128, 128, 768, 64])), dtype=str(rng.choice(["fp32", "fp16", "bf16"])),
+                 lq=int(rng.choice([1, 8, 32, 32])), n=int(rng.choice([1, 2, 9, 100, 1000, 2500])), depth=int(rng.choice([1, 10, 100, 5000])),
+                 form=str(rng.choice(["list", "list", "tensor", "neg", "dup", "cpuQ", "halfQ"])), docs=str(rng.choice(["ragged", "short", "uniform180", "uniform8", "holes"])))
+            for i in range(max(8, int(os.environ.get("MAXSIM_FUZZ_CASES", "48")) // 2))]
+
+
+@pytest.mark.parametrize("c", _rf_cases(), ids=lambda c: f"{c['i']}-h{c['h']}-{c['dtype']}-Lq{c['lq']}-n{c['n']}-d{c['depth']}-{c['form']}-{c['docs']}")
+def test_random_rank_forward(ca, c):
+    """rank_forward(Q[1,h,Lq], pids, depth) -> (list[int], list[float]) (colbert_ranker.py:75-137) against the oracle's
+    restatement of it on the same index: lists and LongTensors, negative pids (torch indexing wraps them), duplicates,
+    depth beyond the list, Q handed over on the CPU or in fp16 (':78' moves and widens it)."""
+    from oracle.maxsim_oracle import RefRanker
+    gen = torch.Generator().manual_seed(8000 + c["i"])
+    tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[c["dtype"]]
+    h, lq, n, depth = c["h"], c["lq"], c["n"], c["depth"]
+    ndocs = 600 if h <= 128 else 200
+    doclens = _doclens(c["docs"], ndocs, gen)
+    if c["docs"] == "holes":
+        doclens = [max(d, 1) for d in doclens]                 # (the reference cannot gather a 0-length doc from a view)
+    half = ndocs // 2
+    pdl = [doclens[:half], doclens[half:]]
+    parts = [F.normalize(torch.randn(sum(d), h, generator=gen), dim=-1).to(tdt) for d in pdl]
+    ref = RefRanker(parts, pdl, dim=h, index_dtype=tdt)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=pdl, dim=h, index_dtype=tdt)
+    q = F.normalize(torch.randn(lq, h, generator=gen), dim=-1)
+    if c["form"] == "dup":
+        pids = torch.randint(0, ndocs, (n,), generator=gen).tolist()
+    else:
+        pids = (torch.randperm(ndocs, generator=gen)[:n] if n <= ndocs else torch.randint(0, ndocs, (n,), generator=gen)).tolist()
+    ref_pids = list(pids)
+    if c["form"] == "neg":                                    # a negative pid p stands for doc ndocs + p (torch indexing)
+        pids = [p - ndocs if i % 3 == 0 else p for i, p in enumerate(pids)]
+    Qr = q.unsqueeze(0).permute(0, 2, 1)                      # [1, h, Lq] as faiss_indexers.py:232-233 hands it over
+    Qin = Qr.cuda()
+    if c["form"] == "cpuQ":
+        Qin = Qr.clone()
+    elif c["form"] == "halfQ":
+        Qin = Qr.cuda().half()
+        Qr = Qin.float().cpu()
+    arg = torch.tensor(pids) if c["form"] == "tensor" else pids
+    got_p, got_s = r.rank_forward(Qin, arg, depth=depth)
+    exp_scores = ref.all_scores(Qr.contiguous(), ref_pids)
+    k = min(depth, len(pids))
+    assert isinstance(got_p, list) and isinstance(got_s, list) and len(got_p) == k and len(got_s) == k
+    atol = ATOL16 if (tdt == torch.bfloat16 and h != 128) else ATOL32
+    es = torch.sort(exp_scores, descending=True).values[:k]
+    np.testing.assert_allclose(np.array(got_s), es.numpy(), rtol=0, atol=atol)
+    assert all(a >= b for a, b in zip(got_s, got_s[1:]))      # sorted by score, descending
+    by_pid = {}
+    for p, s in zip(pids, exp_scores.tolist()):
+        by_pid.setdefault(p, []).append(s)
+    for p, s in zip(got_p, got_s):                            # every returned pid is the caller's own value with ITS score
+        assert p in by_pid and min(abs(s - e) for e in by_pid[p]) <= atol, (p, s)
