@@ -338,3 +338,53 @@ def test_random_rank_forward(ca, c):
         by_pid.setdefault(p, []).append(s)
     for p, s in zip(got_p, got_s):                            # every returned pid is the caller's own value with ITS score
         assert p in by_pid and min(abs(s - e) for e in by_pid[p]) <= atol, (p, s)
+
+
+# ------------------------------------------------------------------------------------------------------
+# the batched driver: ids of the ANN search -> distinct pids -> counted rerank -> counted top-k
+# ------------------------------------------------------------------------------------------------------
+def _retrieve_cases():
+    rng = np.random.RandomState(2718)
+    return [dict(i=i, h=int(rng.choice([128, 128, 768])), dtype=str(rng.choice(["fp32", "fp16"])), bs=int(rng.choice([1, 2, 7, 20])),
+                 lq=int(rng.choice([4, 16, 32])), depth=int(rng.choice([1, 4, 16, 64])), topk=int(rng.choice([1, 10, 100])),
+                 docs=str(rng.choice(["ragged", "short", "uniform8", "uniform180"])), pad=bool(rng.rand() < 0.4))
+            for i in range(max(6, int(os.environ.get("MAXSIM_FUZZ_CASES", "48")) // 4))]
+
+
+@pytest.mark.parametrize("c", _retrieve_cases(), ids=lambda c: f"{c['i']}-h{c['h']}-{c['dtype']}-bs{c['bs']}-Lq{c['lq']}-fd{c['depth']}-k{c['topk']}-{c['docs']}{'-pad' if c['pad'] else ''}")
+def test_random_retrieve_batch(ca, c):
+    """colbert_amd.retrieve_batch against the reference's per-query loop restated on the oracle (dense_server_client.py:44-48
+    -> faiss_indexers.py:224-235 -> colbert_ranker.py:176-229, 75-137): keep_nonzero, the neighbours' token rows -> pids
+    through emb2pid + set(), rank_forward.  The ANN search is a stand-in (random token rows, some -1 as FAISS pads)."""
+    from oracle.maxsim_oracle import RefRanker, keep_nonzero
+    gen = torch.Generator().manual_seed(6000 + c["i"])
+    tdt = torch.float32 if c["dtype"] == "fp32" else torch.float16
+    h, bs, lq, depth, topk = c["h"], c["bs"], c["lq"], c["depth"], c["topk"]
+    ndocs = 500 if h == 128 else 150
+    doclens = [max(d, 1) for d in _doclens(c["docs"], ndocs, gen)]
+    parts = [F.normalize(torch.randn(sum(doclens), h, generator=gen), dim=-1).to(tdt)]
+    ref = RefRanker(parts, [doclens], dim=h, index_dtype=tdt)
+    r = ca.ColbertRanker(parts=parts, parts_doclens=[doclens], dim=h, index_dtype=tdt)
+    Q = F.normalize(torch.randn(bs, lq, h, generator=gen), dim=-1)
+    mask = (torch.rand(bs, lq, generator=gen) < 0.75).long()
+    mask[:, 0] = 1
+    ntok = sum(doclens)
+    ids = torch.randint(0, ntok, (bs, lq, depth), generator=gen)
+    if c["pad"]:
+        ids[torch.rand(bs, lq, depth, generator=gen) < 0.2] = -1
+        ids[:, 0, 0] = torch.randint(0, ntok, (bs,), generator=gen)      # (at least one neighbour per query)
+    emb2pid = torch.repeat_interleave(torch.arange(ndocs), torch.tensor(doclens))            # colbert_ranker.py:163-174
+    out = ca.retrieve_batch(r, Q, mask, topk=topk, embedding_ids=ids)
+    assert len(out) == bs
+    atol = ATOL32
+    for qi in range(bs):
+        q_live, _ = keep_nonzero(Q[qi], mask[qi])                                              # dense_server_client.py:45
+        live_ids = ids[qi][mask[qi].bool()].reshape(-1)
+        live_ids = live_ids[live_ids >= 0]
+        pids = sorted(set(emb2pid[live_ids].tolist()))                                         # :212-229
+        ep, es = ref.rank_forward(q_live.unsqueeze(0).permute(0, 2, 1), pids, depth=topk)     # faiss_indexers.py:232-234
+        gp, gs = out[qi]
+        assert len(gp) == len(ep) == len(gs)
+        np.testing.assert_allclose(np.array(gs), np.array(es), rtol=0, atol=atol)
+        all_s = dict(zip(pids, ref.all_scores(q_live.unsqueeze(0).permute(0, 2, 1), pids).tolist()))
+        assert len(set(gp)) == len(gp) and all(abs(all_s[p] - s) <= atol for p, s in zip(gp, gs))
