@@ -19,6 +19,7 @@ pytestmark = pytest.mark.gpu
 
 ATOL32 = 1e-4
 ATOL16 = 1e-3
+SEED = int(os.environ.get("MAXSIM_FUZZ_SEED", "0"))     # (longer hunts: other cases AND other data than the suite's)
 
 
 @pytest.fixture(scope="module")
@@ -29,7 +30,7 @@ def ca():
 
 
 def _cases():
-    rng = np.random.RandomState(20261004)
+    rng = np.random.RandomState(20261004 + SEED)
     out = []
     for i in range(int(os.environ.get("MAXSIM_FUZZ_CASES", "48"))):     # (more cases: a longer hunt, same seeds first)
         h = int(rng.choice([128, 128, 128, 128, 768, 768, 256, 384, 64, 96]))
@@ -70,7 +71,7 @@ def _doclens(kind, n, gen):
 @pytest.mark.parametrize("c", _cases(), ids=lambda c: f"{c['i']}-h{c['h']}-{c['dtype']}-Lq{c['lq']}-{c['docs']}-{c['nq']}x{c['ncand']}")
 def test_random_launch_shapes(ca, c):
     from oracle.maxsim_oracle import ragged_scores_f64
-    gen = torch.Generator().manual_seed(7000 + c["i"])
+    gen = torch.Generator().manual_seed(7000 + c["i"] + 100003 * SEED)
     h, lq, nq, ncand = c["h"], c["lq"], c["nq"], c["ncand"]
     tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[c["dtype"]]
     ndocs = 1500 if h <= 128 else 400
@@ -155,7 +156,7 @@ def test_random_launch_shapes(ca, c):
 # the operator itself: BaseModel.score (BaseModel.py:39-46), all-pairs, with masks, under random shapes / dtypes
 # ------------------------------------------------------------------------------------------------------
 def _dense_cases():
-    rng = np.random.RandomState(4242)
+    rng = np.random.RandomState(4242 + SEED)
     out = []
     for i in range(int(os.environ.get("MAXSIM_FUZZ_CASES", "48"))):
         h = int(rng.choice([1, 3, 16, 24, 64, 96, 128, 128, 200, 256, 384, 768, 1024, 1100]))
@@ -174,7 +175,7 @@ def test_random_dense_score(ca, c):
     tolerance (fp32 operands 1e-4; 16-bit operands: the oracle evaluated in fp32 on the rounded operands, 1e-3 + the
     result's own 16-bit rounding), and -- where asked -- gradients against torch autograd through the oracle."""
     from oracle.maxsim_oracle import ref_score
-    gen = torch.Generator().manual_seed(9000 + c["i"])
+    gen = torch.Generator().manual_seed(9000 + c["i"] + 100003 * SEED)
     tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[c["dtype"]]
     nq, nd, lq, ld, h = c["nq"], c["nd"], c["lq"], c["ld"], c["h"]
     Q = F.normalize(torch.randn(nq, lq, h, generator=gen), dim=-1).to(tdt)
@@ -244,7 +245,7 @@ def test_backward_on_rows_wider_than_the_backward_kernels(ca):
 # doc-sharded rerank on one GPU: N shards scored one after the other, merged, against ONE whole-index ranker
 # ------------------------------------------------------------------------------------------------------
 def _shard_cases():
-    rng = np.random.RandomState(777)
+    rng = np.random.RandomState(777 + SEED)
     return [dict(i=i, world=int(rng.choice([2, 3, 5, 8])), nq=int(rng.choice([1, 3, 9, 40])), ncand=int(rng.choice([1, 17, 100, 400])),
                  k=int(rng.choice([1, 10, 100])), dtype=str(rng.choice(["fp32", "fp16"])), docs=str(rng.choice(["ragged", "short", "uniform8"])),
                  skew=bool(rng.rand() < 0.4), qdrop=bool(rng.rand() < 0.3))
@@ -258,7 +259,7 @@ def test_random_sharded_rerank(ca, c):
     kernels, so the scores are the same bits; ranks that hold none of a query's candidates contribute padding."""
     from colbert_amd.ranker import reference_strides
     from colbert_amd.sharded import ShardedRanker, merge_gathered, shard_range
-    gen = torch.Generator().manual_seed(5000 + c["i"])
+    gen = torch.Generator().manual_seed(5000 + c["i"] + 100003 * SEED)
     world, nq, ncand, k = c["world"], c["nq"], c["ncand"], c["k"]
     tdt = torch.float32 if c["dtype"] == "fp32" else torch.float16
     ndocs, h = 900, 128
@@ -297,7 +298,7 @@ def test_random_sharded_rerank(ca, c):
 # the online call, as the reference's caller makes it and in the other forms its signature admits
 # ------------------------------------------------------------------------------------------------------
 def _rf_cases():
-    rng = np.random.RandomState(31337)
+    rng = np.random.RandomState(31337 + SEED)
     return [dict(i=i, h=int(rng.choice([128, 128, 768, 64])), dtype=str(rng.choice(["fp32", "fp16", "bf16"])),
                  lq=int(rng.choice([1, 8, 32, 32])), n=int(rng.choice([1, 2, 9, 100, 1000, 2500])), depth=int(rng.choice([1, 10, 100, 5000])),
                  form=str(rng.choice(["list", "list", "tensor", "neg", "dup", "cpuQ", "halfQ"])), docs=str(rng.choice(["ragged", "short", "uniform180", "uniform8", "holes"])))
@@ -310,7 +311,7 @@ def test_random_rank_forward(ca, c):
     restatement of it on the same index: lists and LongTensors, negative pids (torch indexing wraps them), duplicates,
     depth beyond the list, Q handed over on the CPU or in fp16 (':78' moves and widens it)."""
     from oracle.maxsim_oracle import RefRanker
-    gen = torch.Generator().manual_seed(8000 + c["i"])
+    gen = torch.Generator().manual_seed(8000 + c["i"] + 100003 * SEED)
     tdt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[c["dtype"]]
     h, lq, n, depth = c["h"], c["lq"], c["n"], c["depth"]
     ndocs = 600 if h <= 128 else 200
@@ -357,7 +358,7 @@ def test_random_rank_forward(ca, c):
 # the batched driver: ids of the ANN search -> distinct pids -> counted rerank -> counted top-k
 # ------------------------------------------------------------------------------------------------------
 def _retrieve_cases():
-    rng = np.random.RandomState(2718)
+    rng = np.random.RandomState(2718 + SEED)
     return [dict(i=i, h=int(rng.choice([128, 128, 768])), dtype=str(rng.choice(["fp32", "fp16"])), bs=int(rng.choice([1, 2, 7, 20])),
                  lq=int(rng.choice([4, 16, 32])), depth=int(rng.choice([1, 4, 16, 64])), topk=int(rng.choice([1, 10, 100])),
                  docs=str(rng.choice(["ragged", "short", "uniform8", "uniform180"])), pad=bool(rng.rand() < 0.4))
@@ -370,7 +371,7 @@ def test_random_retrieve_batch(ca, c):
     -> faiss_indexers.py:224-235 -> colbert_ranker.py:176-229, 75-137): keep_nonzero, the neighbours' token rows -> pids
     through emb2pid + set(), rank_forward.  The ANN search is a stand-in (random token rows, some -1 as FAISS pads)."""
     from oracle.maxsim_oracle import RefRanker, keep_nonzero
-    gen = torch.Generator().manual_seed(6000 + c["i"])
+    gen = torch.Generator().manual_seed(6000 + c["i"] + 100003 * SEED)
     tdt = torch.float32 if c["dtype"] == "fp32" else torch.float16
     h, bs, lq, depth, topk = c["h"], c["bs"], c["lq"], c["depth"], c["topk"]
     ndocs = 500 if h == 128 else 150
