@@ -169,7 +169,7 @@ def pmc_sweep_child(manifest_path):
         json.dump(manifest, f)
 
 
-def live_pmc(budget_s=300.0):
+def live_pmc(budget_s=180.0):
     """HBM counters measured IN this run: before this process touches the GPU, three short child runs of this same file
     under `rocprofv3 --pmc` -- one counter set per pass, no trace domains, as MI355X_MICROARCH.md's HBM section prescribes:
       fetch  FETCH_SIZE over 1 warm-up + 3 rerank launches of the headline workload AND of every other_workloads entry
