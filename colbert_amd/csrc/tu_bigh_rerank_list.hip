@@ -23,6 +23,8 @@ int launch_list(Params& p, int64_t max_items, hipStream_t st) {
   constexpr int SUB = StreamTraits<DT>::TILE;
   int waves = 0, nt = 0;
   if (!list_shape<DT, NPQ>(p, waves, nt)) return MAXSIM_ERANGE;
+  const bool part = (p.h & 127) != 0;  // last block partial: the one ring shape the static grid uses for such widths
+  if (part) { waves = 4; nt = 1; }
   const int KB = (p.h + 127) / 128;
   const int ldsb = NPQ * KB * SUB + waves * nt * SUB;
   // one workgroup per CU is resident (the query image + rings take most of the LDS): a few rounds of them
@@ -36,6 +38,7 @@ int launch_list(Params& p, int64_t max_items, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
     return check_launch();
   };
+  if (part) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 4, 1, false, 1, true, true>);
   if (waves == 8 && nt == 2) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 8, 2, false, 1, false, true>);
   if (waves == 8) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 8, 1, false, 1, false, true>);
   if (nt == 2) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 4, 2, false, 1, false, true>);
@@ -44,10 +47,10 @@ int launch_list(Params& p, int64_t max_items, hipStream_t st) {
 
 }  // namespace
 
-// Waves per workgroup of the list form for this launch (0: not served -- widths that are not a multiple of 128, or a
-// query image that does not fit), so that the caller can size the workgroup items (docs per item = waves x docs per wave).
+// Waves per workgroup of the list form for this launch (0: not served -- a query image that does not fit), so that the
+// caller can size the workgroup items (docs per item = waves x docs per wave).  Widths that are not a multiple of 128
+// (partial last block) run the 4-wave shape the static grid uses for them.
 int bigh_list_waves(const Params& p, int dt) {
-  if (p.h & 127) return 0;
   const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;
   int waves = 0, nt = 0;
   bool ok;
@@ -56,7 +59,7 @@ int bigh_list_waves(const Params& p, int dt) {
     case MAXSIM_F16: ok = same16 ? list_shape<MAXSIM_F16, 1>(p, waves, nt) : list_shape<MAXSIM_F16, 2>(p, waves, nt); break;
     default: ok = same16 ? list_shape<MAXSIM_BF16, 1>(p, waves, nt) : list_shape<MAXSIM_BF16, 2>(p, waves, nt); break;
   }
-  return ok ? waves : 0;
+  return !ok ? 0 : (p.h & 127) ? 4 : waves;
 }
 
 int launch_bigh_rerank_list(Params& p, int dt, int64_t max_items, hipStream_t st) {
