@@ -265,8 +265,8 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
 #endif
   const bool aligned = (((uintptr_t)Q | (uintptr_t)iv.index) & 15) == 0;  // the streaming kernels move 16-byte pieces
   const bool stream_ok = aligned && Lq >= 1 && Lq <= MAX_LQ_SLICED && n_tokens > 0 && n_tokens <= 0xffffffffLL;
-  // counted rows (doc shards, ANN lists): the device builds a dense list of wave items and a fixed grid walks it.  Ragged
-  // short docs keep the static grid (its half-tile kernel); so does every shape without a streaming kernel for h = 128.
+  // counted rows (doc shards, ANN lists): the device builds a dense list of wave items and a fixed grid walks it (every
+  // shape without a streaming kernel for h = 128 keeps the static grid).
   if (h == 128 && stream_ok && cand_count && worklist && ((uintptr_t)worklist & 15) == 0 && stream_list_serves(p, index_dtype) &&
       worklist_bytes >= maxsim_worklist_bytes(nq, ncand) && ncand < (1 << WL_SLOT_BITS)) {
     p.worklist = worklist;

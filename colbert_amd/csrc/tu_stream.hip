@@ -176,14 +176,12 @@ int launch_list_uni(Params& p, int wgs, hipStream_t st) {
 }
 }  // namespace
 
-// Does the list form serve this index?  Docs longer than 24 tokens on average: the general kernel; shorter: only the
-// uniform 4 / 8 / 16-token kernel on an fp32 index (ragged short docs keep the static grid and its half-tile kernel).
-bool stream_list_serves(const Params& p, int index_dtype) {
-  const bool short_docs = p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs;
-  if (!short_docs) return true;
-  return index_dtype == MAXSIM_F32 && (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16) &&
-         p.n_tokens == (int64_t)p.uniform_len * p.n_docs;
-}
+// Does the list form serve this index?  Always: a uniform 4 / 8 / 16-token fp32 index gets the fixed-length kernel,
+// everything else the general one.  (Ragged short docs on an fp32 index run 5-7 % faster on the static grid's half-tile
+// kernel when every slot is live -- but counted rows come from doc shards and ANN lists, where most slots are not: one
+// rank's share of an 8-way step on docs of 1..24 tokens, 2048 rows with 125 live of 1000 slots, 0.756 -> 0.411 ms with
+// the fp32 index, 0.460 -> 0.180 ms with the fp16 index; tools/probe_share_short_docs.py.)
+bool stream_list_serves(const Params&, int) { return true; }
 
 int stream_list_docs_per_item(const Params& p) {
   double avg = p.n_docs > 0 ? (double)p.n_tokens / (double)p.n_docs : 1.0;
@@ -202,7 +200,8 @@ int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_
   if (wgs < 1) wgs = 1;
   if (wgs > cap) wgs = cap;
   wgs = (wgs + 7) & ~(int64_t)7;  // the kernel's slot -> item map assumes a workgroup's slots share s % 8
-  if (p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs) {  // (stream_list_serves: a uniform short-doc fp32 index)
+  if (p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs && index_dtype == MAXSIM_F32 && p.n_tokens == (int64_t)p.uniform_len * p.n_docs &&
+      (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16)) {  // a uniform short-doc fp32 index
     if (p.uniform_len == 8) return launch_list_uni<8>(p, (int)wgs, st);
     if (p.uniform_len == 4) return launch_list_uni<4>(p, (int)wgs, st);
     return launch_list_uni<16>(p, (int)wgs, st);
