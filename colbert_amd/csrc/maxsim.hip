@@ -272,7 +272,12 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
     p.worklist = worklist;
     const int D0 = stream_list_docs_per_item(p);
     int32_t* const wl = (int32_t*)worklist;
-    hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, wl);
+    // (wave slots the list kernel keeps resident: 2 workgroups of 4 waves per CU; the fixed-length short-doc kernel 4)
+    const bool uni_short = index_dtype == MAXSIM_F32 && p.n_tokens <= 24 * p.n_docs && p.n_tokens == (int64_t)p.uniform_len * p.n_docs &&
+                           (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16);
+    const int slots_knob = MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1);  // (diagnostic builds: 0 switches the one-round rule off)
+    const int list_slots = slots_knob >= 0 ? slots_knob : (uni_short ? 4096 : 2048);
+    hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, list_slots, wl);
     hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
     if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
     const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * LIST_MIN_ITEMS + nq;
@@ -297,7 +302,8 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
       p.worklist = worklist;
       const int D0 = stream_list_docs_per_item(p) * lw;
       int32_t* const wl = (int32_t*)worklist;
-      hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64 * lw, 256, wl);
+      hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64 * lw, 256,
+                         MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) >= 0 ? MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) : 256, wl);  // (one workgroup per CU is resident)
       hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
       if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
       const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * 256 + nq;

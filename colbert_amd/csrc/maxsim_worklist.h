@@ -32,9 +32,11 @@ __device__ __forceinline__ int wl_row_count(const int32_t* __restrict__ counts, 
 
 // One workgroup: (1) the number of live candidates -> docs per wave item D (the host's target D0 = a ~1.4 k-token stream,
 // halved while the launch would have fewer than `min_items` items: a small launch is better off with more, shorter
-// streams -- the rule pick_docs_per_wave applies on the host to static grids); (2) exclusive scan of ceil(count / D).
+// streams -- the rule pick_docs_per_wave applies on the host to static grids; then, for lists of 2-4 rounds of the
+// kernel's `slots` resident wave (workgroup) slots, the cut that wastes the least of the last round --
+// refine_docs_per_wave's reasoning, on the device); (2) exclusive scan of ceil(count / D).
 static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __restrict__ counts, int nq, int ncand, int D0,
-                                                        int Dmax, int min_items, int32_t* __restrict__ wl) {
+                                                        int Dmax, int min_items, int slots, int32_t* __restrict__ wl) {
   __shared__ long long red[16];
   __shared__ int wsum[16];
   __shared__ int carry_s, D_s;
@@ -49,6 +51,24 @@ static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __
     for (int w = 0; w < 16; ++w) t += red[w];
     int D = D0 < 1 ? 1 : (D0 > Dmax ? Dmax : D0);
     while (D > 1 && (t + D - 1) / D < min_items) D = (D + 1) / 2;
+    if (slots > 0 && nq > 0 && t > 0) {
+      // mid-size lists (2-4 rounds of the resident slots): the cut with the smallest rounds x docs per item among D / 2 ..
+      // 2 D, taken when it saves >= 10 % -- with the rows' AVERAGE count standing in for every row (a doc shard's rows
+      // hold ~1000 / N each; for rows of very different lengths the estimate is rough and any D is still correct)
+      const long long cbar = (t + nq - 1) / nq;
+      auto rounds = [&](int d) { return ((long long)nq * ((cbar + d - 1) / d) + slots - 1) / slots; };
+      const long long r0 = rounds(D);
+      if (r0 >= 2 && r0 <= 4) {
+        long long best_cost = r0 * D;
+        int best = D;
+        const int hi = 2 * D < Dmax ? 2 * D : Dmax, lo = D / 2 > 1 ? D / 2 : 1;
+        for (int d = hi; d >= lo; --d) {
+          const long long c = rounds(d) * d;
+          if (c < best_cost) { best_cost = c; best = d; }
+        }
+        if (best_cost * 10 <= r0 * D * 9) D = best;
+      }
+    }
     D_s = D;
     carry_s = 0;
     wl[1] = D;
