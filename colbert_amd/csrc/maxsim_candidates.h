@@ -41,10 +41,12 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
     keys[i] = key;
   }
   __syncthreads();
+  // bitonic network; size and stride are powers of two: shifts and masks, not the integer divisions `i / stride` costs
   for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    for (int ls = 31 - __builtin_clz(size) - 1; ls >= 0; --ls) {
+      const int stride = 1 << ls;
       for (int i = tid; i < (P >> 1); i += nt) {
-        const int lo = ((i / stride) * (stride << 1)) + (i % stride);
+        const int lo = ((i >> ls) << (ls + 1)) | (i & (stride - 1));
         const int hi = lo + stride;
         const bool asc = ((lo & size) == 0);
         const uint32_t a = keys[lo], b = keys[hi];

@@ -9,6 +9,7 @@ Here every step after the ANN search is one launch for the batch: ids -> distinc
 fused rerank of the counted rows with the keep-mask as a per-token predicate (``maxsim_rerank_counted``; nothing is
 compacted, nothing read back), counted top-k, and ONE device->host copy.  The ANN search itself is third-party (FAISS) and stays outside: pass its result, or a callable.
 """
+import numpy as np
 import torch
 
 
@@ -38,14 +39,18 @@ def retrieve_batch(ranker, Q, q_active_padding, topk, embedding_ids=None, ann_se
     else:
         embedding_ids = embedding_ids.to(device=dev, dtype=torch.int64)
         assert embedding_ids.dim() == 3 and tuple(embedding_ids.shape[:2]) == (bs, Lq)
-        embedding_ids = torch.where(keep.unsqueeze(-1), embedding_ids, torch.full_like(embedding_ids, -1))
+        embedding_ids = embedding_ids.masked_fill(~keep.unsqueeze(-1), -1)      # (out of place: the caller's tensor is borrowed)
     # distinct pids per query as COUNTED rows (live pids first, -1 behind): the rerank builds its launch from the counts
     # on the device (maxsim_rerank_counted), so the row width is never read back to trim it -- no host sync before the
     # one copy of the results
     cand, counts = ranker.embedding_ids_to_pids(embedding_ids.reshape(bs, -1), trim=False)   # colbert_ranker.py:178, :212-229
     k = min(int(topk), cand.size(1))
     top_p, top_s = ranker.rerank_batch(Q, cand, depth=k, q_mask=keep, cand_count=counts)      # :75-137 for every query
-    host_p, host_s, host_n = top_p.cpu(), top_s.cpu(), counts.cpu()
+    # ONE device -> host copy (and one wait): pids, score bits and counts packed as int32 words
+    packed = torch.cat([top_p.view(torch.int32), top_s.view(torch.int32), counts.view(torch.int32).unsqueeze(1)], dim=1).cpu().numpy()
+    host_p = np.ascontiguousarray(packed[:, :2 * k]).view(np.int64)
+    host_s = np.ascontiguousarray(packed[:, 2 * k:3 * k]).view(np.float32)
+    host_n = packed[:, 3 * k]
     out = []
     for i in range(bs):
         n = min(k, int(host_n[i]))
