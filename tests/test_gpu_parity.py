@@ -505,7 +505,7 @@ def test_rerank_bsize_candidates(ca, index_dtype):
 # ------------------------------------------------------------------------------------------------------
 # candidate-side glue: colbert_ranker.py:163-174 (emb2pid) + :212-229 (per-query set())
 # ------------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("n", [1, 37, 1000, 4096, 16384])
+@pytest.mark.parametrize("n", [1, 37, 1000, 1025, 2048, 4096, 6000, 8192, 9000, 16384])
 def test_embedding_ids_to_pids(ca, n):
     gen = torch.Generator().manual_seed(n)
     doclens = torch.randint(0, 40, (500,), generator=gen).tolist()       # includes empty docs
