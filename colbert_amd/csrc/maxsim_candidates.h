@@ -4,70 +4,9 @@
 // (:163-174): the pid of a token row is found by binary search in the doclens prefix sum the ranker already holds.
 #pragma once
 #include "maxsim_common.h"
+#include "maxsim_sort.h"
 
 namespace maxsim {
-
-// The bitonic network over P = 1024 E keys with E keys per thread in REGISTERS (thread t owns elements t E .. t E + E - 1):
-// strides below E are compare-exchanges inside a thread (no memory at all), strides below 64 E cross-lane exchanges inside a
-// wave (one ds_bpermute per key, no barrier), and only the strides from 64 E up -- 10 of the 105 passes at P = 16384 -- go
-// through the LDS array with workgroup barriers.  The all-LDS network moves ~13 MB through LDS per 16384-key sort and was
-// ~145 us of a one-query launch's ~210.
-template <int E>
-__device__ __forceinline__ void bitonic_sort_regs(uint32_t* keys, int P, int tid) {
-  uint32_t k[E];
-#pragma unroll
-  for (int j = 0; j < E; ++j) k[j] = keys[tid * E + j];
-  for (int size = 2; size <= P; size <<= 1) {
-    int stride = size >> 1;
-    if (stride >= 64 * E) {  // across waves: through LDS
-#pragma unroll
-      for (int j = 0; j < E; ++j) keys[tid * E + j] = k[j];
-      __syncthreads();
-      for (; stride >= 64 * E; stride >>= 1) {
-        const int ls = 31 - __builtin_clz(stride);
-        for (int i = tid; i < (P >> 1); i += 1024) {
-          const int lo = ((i >> ls) << (ls + 1)) | (i & (stride - 1));
-          const int hi = lo + stride;
-          const bool asc = ((lo & size) == 0);
-          const uint32_t a = keys[lo], b = keys[hi];
-          if (asc ? (a > b) : (a < b)) { keys[lo] = b; keys[hi] = a; }
-        }
-        __syncthreads();
-      }
-#pragma unroll
-      for (int j = 0; j < E; ++j) k[j] = keys[tid * E + j];
-    }
-    for (; stride >= E; stride >>= 1) {  // across the lanes of a wave
-      const int lx = stride / E;
-      const bool is_lo = (tid & lx) == 0;
-      const bool asc = ((tid * E) & size) == 0;  // (size >= 2 stride >= 2 E: the same for the thread's E keys)
-      const bool keep_min = asc == is_lo;
-#pragma unroll
-      for (int j = 0; j < E; ++j) {
-        const uint32_t v = (uint32_t)__shfl_xor((int)k[j], lx);
-        k[j] = keep_min ? min(k[j], v) : max(k[j], v);
-      }
-    }
-#pragma unroll
-    for (int s = E / 2; s >= 1; s >>= 1) {  // inside the thread (s is a compile-time number in every unrolled copy)
-      if (s <= (size >> 1)) {
-#pragma unroll
-        for (int j = 0; j < E; ++j) {
-          if ((j & s) == 0) {
-            const bool asc = ((tid * E + j) & size) == 0;
-            const uint32_t a = k[j], b = k[j | s];
-            const uint32_t mn = min(a, b), mx = max(a, b);
-            k[j] = asc ? mn : mx;
-            k[j | s] = asc ? mx : mn;
-          }
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < E; ++j) keys[tid * E + j] = k[j];
-  __syncthreads();
-}
 
 // One workgroup per query.  keys: P (power of two >= n) uint32 in LDS, 0xFFFFFFFF = dropped id.
 // Output: the query's distinct pids in ascending order, then -1 padding; out_count[q] = number of distinct pids.
@@ -105,10 +44,10 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
   __syncthreads();
   // bitonic network: keys in registers where the workgroup is full (P >= 2048), else all in LDS; size and stride are powers
   // of two: shifts and masks, not the integer divisions `i / stride` costs
-  if (nt == 1024 && P == 16384) bitonic_sort_regs<16>(keys, P, tid);
-  else if (nt == 1024 && P == 8192) bitonic_sort_regs<8>(keys, P, tid);
-  else if (nt == 1024 && P == 4096) bitonic_sort_regs<4>(keys, P, tid);
-  else if (nt == 1024 && P == 2048) bitonic_sort_regs<2>(keys, P, tid);
+  if (nt == 1024 && P == 16384) bitonic_sort_regs<16, uint32_t, false>(keys, P, tid);
+  else if (nt == 1024 && P == 8192) bitonic_sort_regs<8, uint32_t, false>(keys, P, tid);
+  else if (nt == 1024 && P == 4096) bitonic_sort_regs<4, uint32_t, false>(keys, P, tid);
+  else if (nt == 1024 && P == 2048) bitonic_sort_regs<2, uint32_t, false>(keys, P, tid);
   else
   for (int size = 2; size <= P; size <<= 1) {
     for (int ls = 31 - __builtin_clz(size) - 1; ls >= 0; --ls) {

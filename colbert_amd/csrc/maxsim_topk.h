@@ -1,6 +1,7 @@
 // maxsim_topk.h -- per-query top-k (colbert_ranker.py:128-130) and small utility kernels.
 #pragma once
 #include "maxsim_common.h"
+#include "maxsim_sort.h"
 
 namespace maxsim {
 
@@ -131,10 +132,17 @@ __global__ void __launch_bounds__(1024) k_topk(const float* __restrict__ scores,
     keys[i] = key;
   }
   __syncthreads();
+  // descending bitonic sort: in registers (maxsim_sort.h) where the row fills the workgroup, else in LDS
+  if (nt == 1024 && P == 16384) bitonic_sort_regs<16, uint64_t, true>(keys, P, tid);
+  else if (nt == 1024 && P == 8192) bitonic_sort_regs<8, uint64_t, true>(keys, P, tid);
+  else if (nt == 1024 && P == 4096) bitonic_sort_regs<4, uint64_t, true>(keys, P, tid);
+  else if (nt == 1024 && P == 2048) bitonic_sort_regs<2, uint64_t, true>(keys, P, tid);
+  else
   for (int size = 2; size <= P; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+    for (int ls = 31 - __builtin_clz(size) - 1; ls >= 0; --ls) {
+      const int stride = 1 << ls;
       for (int i = tid; i < (P >> 1); i += nt) {
-        int lo = ((i / stride) * (stride << 1)) + (i % stride);
+        int lo = ((i >> ls) << (ls + 1)) | (i & (stride - 1));
         int hi = lo + stride;
         bool desc = ((lo & size) == 0);  // descending overall
         uint64_t a = keys[lo], b = keys[hi];
