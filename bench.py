@@ -801,9 +801,23 @@ def retrieve_step_probe(ranker, Q, dev, faiss_depth=512, hot=1500):
     a = t(lambda: ranker.embedding_ids_to_pids(ids, trim=False))
     b = t(lambda: ranker.score_candidates(Q, cand, cand_count=cnt))
     c = t(lambda: ranker.topk(sc, cand, TOPK, cnt))
+    # the same driver serving ONE query at a time (the reference's server loop, dense_server_client.py:56-63): the whole
+    # colbert_amd.retrieve_batch call, ids on the device in, python lists on the host out -- wall clock, median of 30
+    import colbert_amd
+    ids1 = ids[:1].view(1, Q.size(1), faiss_depth)
+    keep1 = torch.ones(1, Q.size(1), dtype=torch.long, device=dev)
+    for _ in range(5):
+        colbert_amd.retrieve_batch(ranker, Q[:1], keep1, topk=TOPK, embedding_ids=ids1)
+    lat = []
+    for _ in range(30):
+        t0 = time.perf_counter()
+        colbert_amd.retrieve_batch(ranker, Q[:1], keep1, topk=TOPK, embedding_ids=ids1)
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
     return {"shape": f"{nq} queries x {n} ANN ids (faiss_depth {faiss_depth}), {float(cnt.float().mean()):.0f} distinct candidates per query",
             "ids_to_pids_ms": round(a, 4), "counted_rerank_ms": round(b, 4), "counted_topk_ms": round(c, 4),
-            "step_ms": round(a + b + c, 4), "queries_per_s": round(nq / ((a + b + c) * 1e-3), 1)}
+            "step_ms": round(a + b + c, 4), "queries_per_s": round(nq / ((a + b + c) * 1e-3), 1),
+            "one_query_end_to_end_ms": round(lat[len(lat) // 2] * 1e3, 4)}
 
 
 def single_query_probe(ranker, Q, cands, H, LQ, esize):
