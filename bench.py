@@ -492,6 +492,61 @@ def sharded_share(colbert_amd, ranker, ndocs, dev, lq, h, esize, steps, warmup, 
     return out
 
 
+def sharded_from_files_check(colbert_amd, dev, rank, world, one_gpu):
+    """N > 1 only: the shipped sharded path from the reference's index FILES to python lists, over the job's own process
+    group (RCCL).  Rank 0 writes a small ragged index in the reference's format ({i}.pt + doclens.{i}.json, 4 parts) to
+    the node's /tmp; every rank ``load_shard``s its pid range from it and all ranks call ``ShardedRanker.rank_forward``
+    (1000 global pids) and ``ShardedRanker.retrieve_batch`` (16 queries x 32 x 64 GLOBAL token rows, masked query tokens);
+    every rank also loads the whole index as one ``ColbertRanker`` and compares: the sharded results must equal the
+    unsharded HIP path's.  A self-check of shipped code on the multi-GPU run, not a timed leg and not the oracle."""
+    from colbert_amd.index_io import save_index
+    from colbert_amd.sharded import load_shard
+    path = os.path.join("/tmp", f"maxsim_bench_index_{os.environ.get('MASTER_PORT', '0')}")
+    g = torch.Generator().manual_seed(21)
+    ndocs, nparts, h, lq = 4096, 4, 128, 32
+    doclens = (torch.randn(ndocs, generator=g) * 40 + 100).round().clamp(4, 180).long().tolist()
+    cut = [0, 1000, 2048, 2500, ndocs]                      # part boundaries that are not shard boundaries
+    if rank == 0:
+        parts_dl = [doclens[cut[i]:cut[i + 1]] for i in range(nparts)]
+        parts = [F.normalize(torch.randn(sum(dl), h, generator=g), dim=-1).half() for dl in parts_dl]
+        save_index(path, parts, parts_dl)
+        del parts
+    dist.barrier()
+    sh = load_shard(path, device=dev)                        # rank / world from the process group
+    whole = colbert_amd.ColbertRanker(index_path=path, device=dev)
+    gq = torch.Generator().manual_seed(22)                   # same inputs on every rank
+    Q1 = F.normalize(torch.randn(1, lq, h, generator=gq), dim=-1).to(dev).permute(0, 2, 1)
+    pids = torch.randperm(ndocs, generator=gq)[:1000].tolist()
+    got = sh.rank_forward(Q1, pids, depth=TOPK)
+    exp = whole.rank_forward(Q1, pids, depth=TOPK)
+    rf_ok = got[1] == exp[1] and sorted(got[0]) == sorted(exp[0])
+    nq, depth = 16, 64
+    Qb = F.normalize(torch.randn(nq, lq, h, generator=gq), dim=-1).to(dev)
+    keep = (torch.rand(nq, lq, generator=gq) > 0.25).long().to(dev)
+    hot = torch.randint(0, ndocs, (nq, 300), generator=gq)
+    offs = torch.tensor([0] + doclens).cumsum(0)
+    docs = hot.gather(1, torch.randint(0, 300, (nq, lq * depth), generator=gq))
+    ids = (offs[docs] + (torch.rand(nq, lq * depth, generator=gq) * torch.tensor(doclens)[docs]).long()).view(nq, lq, depth).to(dev)
+    t0 = time.perf_counter()
+    got_b = sh.retrieve_batch(Qb, keep, TOPK, embedding_ids=ids)
+    rb_ms = (time.perf_counter() - t0) * 1e3
+    exp_b = colbert_amd.retrieve_batch(whole, Qb, keep, TOPK, embedding_ids=ids)
+    rb_ok = all(gs == es and sorted(gp) == sorted(ep) and dict(zip(gp, gs)) == dict(zip(ep, es))
+                for (gp, gs), (ep, es) in zip(got_b, exp_b))
+    flags = torch.tensor([int(rf_ok), int(rb_ok)], dtype=torch.int64, device="cpu" if one_gpu else dev)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    dist.barrier()
+    if rank == 0:
+        for f in os.listdir(path):
+            os.remove(os.path.join(path, f))
+        os.rmdir(path)
+    return {"what": "load_shard from {i}.pt/doclens.{i}.json on every rank; ShardedRanker.rank_forward + retrieve_batch over the job's "
+                    "process group vs the unsharded ColbertRanker over the same files (ties aside: equal score lists, equal pid sets)",
+            "docs": ndocs, "parts": nparts, "rank_forward_equal_on_all_ranks": bool(flags[0].item()),
+            "retrieve_batch_equal_on_all_ranks": bool(flags[1].item()), "retrieve_batch_first_call_ms": round(rb_ms, 3),
+            "shard_of_rank0": [sh.lo, sh.hi], "strides": list(sh.local.strides)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -686,6 +741,13 @@ def main():
                     "exchange_merge_ms": [round(float(r[1]), 4) for r in rows],
                     "local_candidates_per_query": [round(float(r[2]), 2) for r in rows]}
 
+    files_check = None
+    if use_dist:
+        try:
+            files_check = sharded_from_files_check(colbert_amd, dev, rank, world, one_gpu)
+        except Exception as e:        # a failed self-check is reported in the line, it must not lose the measurement
+            files_check = {"error": f"{type(e).__name__}: {e}"}
+
     default_shape = ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand or args.ld or args.q_dtype) and (world == 1)
     suffix = f"_shard{job_world}" if sim else ""
     rf = roofline_entry(kern_ms, alg_bytes, cand_tokens, LQ, H, args.workload, args.index_dtype, args.fp32_mode,
@@ -720,6 +782,7 @@ def main():
             res["n_ranks_seen"] = dist.get_world_size()
             res["backend"] = dist.get_backend()
             res["per_rank"] = per_rank
+            res["sharded_from_files"] = files_check
         if strat is not None:
             res["stratified"] = strat
         full = world == 1 and args.workload == "c2" and not args.no_cpu_baseline and not sim and default_shape

@@ -5,5 +5,6 @@ from . import _lib
 from .ranker import ColbertRanker
 from .retriever import retrieve_batch
 from .scoring import MaxSimModel, score
+from .sharded import ShardedRanker, load_shard
 
-__all__ = ["ColbertRanker", "MaxSimModel", "score", "retrieve_batch", "_lib"]
+__all__ = ["ColbertRanker", "MaxSimModel", "score", "retrieve_batch", "ShardedRanker", "load_shard", "_lib"]

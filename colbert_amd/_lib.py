@@ -19,7 +19,8 @@ SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_re
            "maxsim_score_dense_bwd_workspace", "maxsim_rerank_ex", "maxsim_rank_forward", "maxsim_rank_forward_workspace_bytes", "maxsim_doc_table_bytes",
            "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel", "maxsim_worklist_bytes",
            "maxsim_rerank_counted", "maxsim_topk_counted", "maxsim_hbm_read_probe", "maxsim_hbm_read_probe_scattered",
-           "maxsim_host_alloc_coherent", "maxsim_host_free")
+           "maxsim_host_alloc_coherent", "maxsim_host_free", "maxsim_embedding_ids_to_pids_ex", "maxsim_row_blocks_bytes",
+           "maxsim_build_row_blocks")
 
 
 class IndexView(ctypes.Structure):
@@ -93,6 +94,12 @@ def _load():
     lib.maxsim_hbm_read_probe_scattered.argtypes = [vp, i64, i32, i32, i64, vp]
     lib.maxsim_embedding_ids_to_pids.restype = i32
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
+    lib.maxsim_embedding_ids_to_pids_ex.restype = i32
+    lib.maxsim_embedding_ids_to_pids_ex.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, i64, vp, vp, vp, vp]
+    lib.maxsim_row_blocks_bytes.restype = i64
+    lib.maxsim_row_blocks_bytes.argtypes = [i64]
+    lib.maxsim_build_row_blocks.restype = i32
+    lib.maxsim_build_row_blocks.argtypes = [vp, i64, i64, vp, vp]
     return lib
 
 

@@ -524,22 +524,50 @@ int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* 
   return check_launch();
 }
 
-int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,
-                                 int64_t n_tokens, int64_t* out_pids, int32_t* out_count, void* stream) {
+int64_t maxsim_row_blocks_bytes(int64_t n_tokens) {
+  if (n_tokens < 0) return MAXSIM_EINVAL;
+  return (((n_tokens + (1 << kRowBlockShift) - 1) >> kRowBlockShift) + 1) * 4;
+}
+
+int maxsim_build_row_blocks(const int64_t* tok_offsets, int64_t n_docs, int64_t n_tokens, void* row_blocks, void* stream) {
+  if (n_docs < 0 || n_tokens < 0 || !row_blocks || (n_docs > 0 && !tok_offsets)) return MAXSIM_EINVAL;
+  if (n_docs > 0xfffffffeLL) return MAXSIM_ERANGE;
+  const int64_t nblocks = (n_tokens + (1 << kRowBlockShift) - 1) >> kRowBlockShift;
+  const int64_t wgs = (nblocks + 1 + 255) / 256;
+  if (wgs > 0x7fffffffLL) return MAXSIM_ERANGE;
+  hipLaunchKernelGGL(k_build_row_blocks, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, tok_offsets, n_docs, nblocks,
+                     (uint32_t*)row_blocks);
+  return check_launch();
+}
+
+int maxsim_embedding_ids_to_pids_ex(const int64_t* emb_ids, int nq, int n, int ids_per_token, const uint8_t* tok_keep,
+                                    int64_t id_base, const int64_t* tok_offsets, int64_t n_docs, int64_t n_tokens,
+                                    const void* row_blocks, int64_t* out_pids, int32_t* out_count, void* stream) {
   if (nq < 0 || n < 0 || n_docs < 0 || n_tokens < 0) return MAXSIM_EINVAL;
   if (n == 0) return MAXSIM_EEMPTY;
   if (n > 16384 || n_docs > 0xfffffffeLL) return MAXSIM_ERANGE;
+  if (tok_keep && (ids_per_token <= 0 || n % ids_per_token != 0)) return MAXSIM_EINVAL;
   if (nq == 0) return MAXSIM_OK;
-  if (!emb_ids || !tok_offsets || !out_pids || !out_count) return MAXSIM_EINVAL;
-  int P = 2;
+  if (!emb_ids || !out_pids || !out_count || (n_docs > 0 && !tok_offsets)) return MAXSIM_EINVAL;
+  int P = 2048;
   while (P < n) P <<= 1;
-  const int threads = P / 2 < 64 ? 64 : (P / 2 > 1024 ? 1024 : P / 2);
-  const int ldsb = P * 4 + threads * 4;
+  int log_ts = 12;                                         // hash set: min(16384, 2 P) slots
+  while ((1 << log_ts) < 2 * P && log_ts < 14) ++log_ts;
+  const int ldsb = ((1 << log_ts) + 1024 + 4) * 4;
+  int ipt_arg = tok_keep ? ids_per_token : 1;              // a power of two travels as -(log2) - 1: a shift in the kernel
+  if ((ipt_arg & (ipt_arg - 1)) == 0) ipt_arg = -__builtin_ctz((unsigned)ipt_arg) - 1;
   int rc = allow_lds(k_unique_pids, ldsb);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_unique_pids, dim3((unsigned)nq), dim3(threads), ldsb, (hipStream_t)stream, emb_ids, n, P,
-                     tok_offsets, n_docs, n_tokens, out_pids, out_count);
+  hipLaunchKernelGGL(k_unique_pids, dim3((unsigned)nq), dim3(1024), ldsb, (hipStream_t)stream, emb_ids, n, P, log_ts, id_base,
+                     tok_keep, ipt_arg, tok_offsets, n_docs, n_tokens, (const uint32_t*)row_blocks, out_pids,
+                     out_count);
   return check_launch();
+}
+
+int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,
+                                 int64_t n_tokens, int64_t* out_pids, int32_t* out_count, void* stream) {
+  return maxsim_embedding_ids_to_pids_ex(emb_ids, nq, n, 1, nullptr, 0, tok_offsets, n_docs, n_tokens, nullptr, out_pids,
+                                         out_count, stream);
 }
 
 }  // extern "C"

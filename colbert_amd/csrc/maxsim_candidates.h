@@ -1,32 +1,64 @@
 // maxsim_candidates.h -- candidate-side glue: ANN embedding ids -> per-query unique pid lists, on the GPU.
 // Replaces ColbertIndex.embedding_ids_to_pids (reference: colbert/ranking/colbert_ranker.py:212-229: emb2pid
 // lookup, .tolist(), per-query set() in a Pool(16)) and the 4-byte-per-token emb2pid table of build_emb2pid
-// (:163-174): the pid of a token row is found by binary search in the doclens prefix sum the ranker already holds.
+// (:163-174): the pid of a token row comes from a 64x coarser table (one entry per 64 token rows, k_build_row_blocks)
+// and a search of the doclens prefix sum inside that block -- ~3 loads -- or, without the table, a binary search over
+// the whole prefix sum (~20 loads).
 #pragma once
 #include "maxsim_common.h"
 #include "maxsim_sort.h"
 
 namespace maxsim {
 
-// One workgroup per query.  keys: P (power of two >= n) uint32 in LDS, 0xFFFFFFFF = dropped id.
-// Output: the query's distinct pids in ascending order, then -1 padding; out_count[q] = number of distinct pids.
-__global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict__ emb_ids, int n, int P,
-                                                      const int64_t* __restrict__ tok_offsets, int64_t n_docs,
-                                                      int64_t n_tokens, int64_t* __restrict__ out_pids,
-                                                      int32_t* __restrict__ out_count) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  uint32_t* keys = (uint32_t*)lds;            // [P]
-  uint32_t* scan = keys + P;                  // [blockDim.x]
-  const int q = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
-  // pid of a token row e = (number of docs whose first row is <= e) - 1 (skipping empty docs that start at the same row):
-  // a binary search in the doclens prefix sum, ~20 dependent 8-byte loads for a million docs -- and with the ids in ANN
-  // order every lane of a load instruction hits a different cache line: 16384 x 20 loads cost the CU's address pipeline
-  // ~0.2 ms of a 0.46 ms launch.  The pid is monotone in the token row, so when the rows fit 32 bits the ROWS are sorted
-  // first and looked up afterwards: neighbouring lanes then walk neighbouring table entries (the same few lines per
-  // instruction), and the distinct step below sees the same sorted pids.
+constexpr int kRowBlockShift = 6;  // one row-block table entry per 64 token rows
+constexpr uint32_t kNoKey = 0xFFFFFFFFu;
+
+// row_blocks[b] = the doc that holds token row b * 64 (the LAST doc whose first row is <= it: empty docs that start at the
+// same row come before the one that owns it), b = 0 .. nblocks - 1; row_blocks[nblocks] = n_docs - 1.
+__global__ void __launch_bounds__(256) k_build_row_blocks(const int64_t* __restrict__ tok_offsets, int64_t n_docs,
+                                                          int64_t nblocks, uint32_t* __restrict__ row_blocks) {
+  const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (b > nblocks) return;
+  const int64_t e = b << kRowBlockShift;
+  int64_t lo = 0, hi = n_docs;  // invariant: tok_offsets[i] <= e for i < lo ; > e for i >= hi
+  if (b == nblocks) lo = n_docs;
+  else
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (tok_offsets[mid] <= e) lo = mid + 1; else hi = mid;
+    }
+  row_blocks[b] = (uint32_t)(lo > 0 ? lo - 1 : 0);
+}
+
+// The token row (relative to id_base) behind slot i of query q, or -1: FAISS pads missing neighbours with -1, rows of
+// another shard fall outside [0, n_tokens), and the neighbours of a dropped query token (tok_keep[q, i / ids_per_token]
+// == 0: keep_nonzero, training_utils.py:48-53) do not count.
+__device__ __forceinline__ int64_t candidate_row(const int64_t* __restrict__ emb_ids, int q, int n, int i, int64_t id_base,
+                                                 const uint8_t* __restrict__ tok_keep, int ids_per_token, int64_t n_tokens) {
+  if (i >= n) return -1;
+  if (tok_keep != nullptr) {   // ids_per_token < 0: -(log2 of it) - 1, a shift instead of the division (faiss_depth is 2^k as a rule)
+    const int tok = ids_per_token < 0 ? i >> (-ids_per_token - 1) : i / ids_per_token;
+    const int ntok = ids_per_token < 0 ? n >> (-ids_per_token - 1) : n / ids_per_token;
+    if (tok_keep[(int64_t)q * ntok + tok] == 0) return -1;
+  }
+  const int64_t e = emb_ids[(int64_t)q * n + i] - id_base;
+  return (e >= 0 && e < n_tokens) ? e : -1;
+}
+
+// Ascending distinct pids of keys[0 .. P) (kNoKey = nothing) by sorting ALL P keys: the path of a query whose ids hit
+// more distinct docs than the hash set below holds.  1024 threads, P in {2048 .. 16384}.
+__device__ __forceinline__ void unique_by_full_sort(uint32_t* keys, uint32_t* scan, int q, int n, int P, const int64_t* __restrict__ emb_ids,
+                                                 int64_t id_base, const uint8_t* __restrict__ tok_keep, int ids_per_token,
+                                                 const int64_t* __restrict__ tok_offsets, int64_t n_docs, int64_t n_tokens,
+                                                 int64_t* __restrict__ out_pids, int32_t* __restrict__ out_count) {
+  const int tid = threadIdx.x;
+  constexpr int nt = 1024;
+  // The pid is monotone in the token row, so when the rows fit 32 bits the ROWS are sorted first and looked up afterwards:
+  // neighbouring lanes then walk neighbouring table entries (the same few cache lines per load instruction) instead of
+  // 64 different lines, and the distinct step below sees the same sorted pids.
   const bool rows_first = n_tokens < 0xFFFFFFFFll;
   auto pid_of = [&](int64_t e) {
-    int64_t lo = 0, hi = n_docs;               // invariant: tok_offsets[lo'] <= e for lo' < lo ; > e for >= hi
+    int64_t lo = 0, hi = n_docs;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       if (tok_offsets[mid] <= e) lo = mid + 1; else hi = mid;
@@ -34,34 +66,14 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
     return (uint32_t)(lo - 1);
   };
   for (int i = tid; i < P; i += nt) {
-    uint32_t key = 0xFFFFFFFFu;
-    if (i < n) {
-      const int64_t e = emb_ids[(int64_t)q * n + i];
-      if (e >= 0 && e < n_tokens) key = rows_first ? (uint32_t)e : pid_of(e);   // FAISS pads missing neighbours with -1
-    }
-    keys[i] = key;
+    const int64_t e = candidate_row(emb_ids, q, n, i, id_base, tok_keep, ids_per_token, n_tokens);
+    keys[i] = e < 0 ? kNoKey : (rows_first ? (uint32_t)e : pid_of(e));
   }
   __syncthreads();
-  // bitonic network: keys in registers where the workgroup is full (P >= 2048), else all in LDS; size and stride are powers
-  // of two: shifts and masks, not the integer divisions `i / stride` costs
-  if (nt == 1024 && P == 16384) bitonic_sort_regs<16, uint32_t, false>(keys, P, tid);
-  else if (nt == 1024 && P == 8192) bitonic_sort_regs<8, uint32_t, false>(keys, P, tid);
-  else if (nt == 1024 && P == 4096) bitonic_sort_regs<4, uint32_t, false>(keys, P, tid);
-  else if (nt == 1024 && P == 2048) bitonic_sort_regs<2, uint32_t, false>(keys, P, tid);
-  else
-  for (int size = 2; size <= P; size <<= 1) {
-    for (int ls = 31 - __builtin_clz(size) - 1; ls >= 0; --ls) {
-      const int stride = 1 << ls;
-      for (int i = tid; i < (P >> 1); i += nt) {
-        const int lo = ((i >> ls) << (ls + 1)) | (i & (stride - 1));
-        const int hi = lo + stride;
-        const bool asc = ((lo & size) == 0);
-        const uint32_t a = keys[lo], b = keys[hi];
-        if (asc ? (a > b) : (a < b)) { keys[lo] = b; keys[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
+  if (P == 16384) bitonic_sort_regs<16, uint32_t, false>(keys, P, tid);
+  else if (P == 8192) bitonic_sort_regs<8, uint32_t, false>(keys, P, tid);
+  else if (P == 4096) bitonic_sort_regs<4, uint32_t, false>(keys, P, tid);
+  else bitonic_sort_regs<2, uint32_t, false>(keys, P, tid);
   if (rows_first) {  // sorted token rows -> their (sorted) pids, in place.  A thread runs its searches G at a time in
     // lock-step (every round issues G independent loads, no branches): the chain it waits for is ~20 loads, not 20 x P / nt
     constexpr int G = 8;
@@ -73,8 +85,8 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
 #pragma unroll
       for (int g = 0; g < G; ++g) {
         const int i = i0 + g * nt;
-        const uint32_t k32 = i < P ? keys[i] : 0xFFFFFFFFu;
-        e[g] = k32 == 0xFFFFFFFFu ? -1 : (int64_t)k32;
+        const uint32_t k32 = i < P ? keys[i] : kNoKey;
+        e[g] = k32 == kNoKey ? -1 : (int64_t)k32;
         lo[g] = 0;
         hi[g] = e[g] >= 0 ? n_docs : 0;
       }
@@ -101,12 +113,12 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
     __syncthreads();
   }
   // distinct keys: each thread owns a contiguous run of P / nt elements
-  const int per = (P + nt - 1) / nt;
-  const int b0 = tid * per, b1 = min(P, b0 + per);
+  const int per = P / nt;
+  const int b0 = tid * per, b1 = b0 + per;
   uint32_t cnt = 0;
   for (int i = b0; i < b1; ++i) {
     const uint32_t k = keys[i];
-    cnt += (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
+    cnt += (k != kNoKey && (i == 0 || keys[i - 1] != k)) ? 1u : 0u;
   }
   scan[tid] = cnt;
   __syncthreads();
@@ -120,9 +132,140 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
   uint32_t pos = scan[tid] - cnt;
   for (int i = b0; i < b1; ++i) {
     const uint32_t k = keys[i];
-    if (k != 0xFFFFFFFFu && (i == 0 || keys[i - 1] != k)) out_pids[(int64_t)q * n + pos++] = (int64_t)k;
+    if (k != kNoKey && (i == 0 || keys[i - 1] != k)) out_pids[(int64_t)q * n + pos++] = (int64_t)k;
   }
   for (int i = (int)total + tid; i < n; i += nt) out_pids[(int64_t)q * n + i] = -1;
+  if (tid == 0) out_count[q] = (int32_t)total;
+}
+
+// One workgroup of 1024 threads per query.  The ANN result of a query names each of its docs several times (32 tokens x
+// faiss_depth 512 = 16384 ids over a few thousand docs), and the reference wants the SET (colbert_ranker.py:234): the ids
+// are looked up and de-duplicated FIRST, in an LDS hash set (open addressing, one ds_cmpst per probe), and only the
+// distinct pids are sorted -- e.g. a 2048-key register network instead of the 16384-key one (105 passes) that sorting
+// every id costs.  The set has TS = min(16384, 2 P) slots; it is compacted in place (every thread holds its slots in
+// registers across a barrier), so the keys to sort re-use the table's memory.  A query that fills the set beyond what
+// linear probing handles (a probe chain > 64: ~14000 distinct docs of 16384 ids) takes unique_by_full_sort instead: same
+// result, old speed.
+// Output: the query's distinct pids in ascending order, then -1 padding; out_count[q] = number of distinct pids.
+// LDS: buf[TS] u32 (TS >= P: the full-sort path re-uses it as keys[P]), scan[1024] u32, flags.
+__global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict__ emb_ids, int n, int P, int log_ts,
+                                                      int64_t id_base, const uint8_t* __restrict__ tok_keep, int ids_per_token,
+                                                      const int64_t* __restrict__ tok_offsets, int64_t n_docs,
+                                                      int64_t n_tokens, const uint32_t* __restrict__ row_blocks,
+                                                      int64_t* __restrict__ out_pids, int32_t* __restrict__ out_count) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int nt = 1024;
+  const int TS = 1 << log_ts;
+  uint32_t* table = (uint32_t*)lds;            // [TS]
+  uint32_t* keys = table;                      // the compacted set, in place
+  uint32_t* scan = table + TS;                 // [1024]
+  uint32_t* flags = scan + nt;                 // [0] = overflow
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int i = tid; i < TS; i += nt) table[i] = kNoKey;
+  if (tid == 0) flags[0] = 0;
+  __syncthreads();
+
+  // ---- look up and insert, G ids per thread at a time (their loads are independent: one latency per round, not per id)
+  constexpr int G = 8;
+  const int64_t last = n_docs - 1;
+  for (int i0 = tid; i0 < n; i0 += G * nt) {
+    int64_t e[G];
+    uint32_t lo[G], hi[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) e[g] = candidate_row(emb_ids, q, n, i0 + g * nt, id_base, tok_keep, ids_per_token, n_tokens);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      lo[g] = 0;
+      hi[g] = e[g] >= 0 ? (uint32_t)last : 0u;
+      if (row_blocks != nullptr && e[g] >= 0) {
+        lo[g] = row_blocks[e[g] >> kRowBlockShift];
+        hi[g] = row_blocks[(e[g] >> kRowBlockShift) + 1];
+      }
+    }
+    // the doc of row e: the LAST pid in [lo, hi] whose first row is <= e (tok_offsets[lo] <= e holds on entry)
+    bool open = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) open |= lo[g] < hi[g];
+    while (__any(open)) {
+      uint32_t mid[G];
+      int64_t off[G];
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        mid[g] = lo[g] + ((hi[g] - lo[g] + 1) >> 1);
+        off[g] = lo[g] < hi[g] ? tok_offsets[mid[g]] : 0;
+      }
+      open = false;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (lo[g] < hi[g]) {
+          if (off[g] <= e[g]) lo[g] = mid[g]; else hi[g] = mid[g] - 1;
+        }
+        open |= lo[g] < hi[g];
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (e[g] < 0) continue;
+      const uint32_t pid = lo[g];
+      uint32_t h = (pid * 2654435761u) >> (32 - log_ts);
+      int probes = 0;
+      for (;;) {
+        const uint32_t prev = atomicCAS(&table[h], kNoKey, pid);
+        if (prev == kNoKey || prev == pid) break;
+        h = (h + 1) & (TS - 1);
+        if (++probes > 64) { flags[0] = 1; break; }   // the set is (nearly) full: this query takes the full sort
+      }
+    }
+  }
+  __syncthreads();
+  if (flags[0] != 0) {
+    __syncthreads();
+    unique_by_full_sort((uint32_t*)lds, scan, q, n, P, emb_ids, id_base, tok_keep, ids_per_token, tok_offsets, n_docs, n_tokens,
+                        out_pids, out_count);
+    return;
+  }
+
+  // ---- compact the set in place: thread t owns table slots [t * spt, (t + 1) * spt), spt = 4 / 8 / 16
+  const int spt = TS / nt;
+  uint32_t v[16];
+  uint32_t cnt = 0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    v[j] = j < spt ? table[tid * spt + j] : kNoKey;
+    cnt += v[j] != kNoKey ? 1u : 0u;
+  }
+  uint32_t incl = cnt;                          // inclusive scan inside the wave, then over the 16 waves' totals
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t u = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += u;
+  }
+  if ((tid & 63) == 63) scan[tid >> 6] = incl;
+  __syncthreads();                              // (also: every thread has read its slots)
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < nt / 64; ++w) {
+    const uint32_t u = scan[w];
+    base += w < (tid >> 6) ? u : 0u;
+    total += u;
+  }
+  uint32_t pos = base + incl - cnt;
+#pragma unroll
+  for (int j = 0; j < 16; ++j)
+    if (v[j] != kNoKey) keys[pos++] = v[j];
+  int P2 = 1024;
+  while (P2 < (int)total) P2 <<= 1;
+  for (int i = (int)total + tid; i < P2; i += nt) keys[i] = kNoKey;
+  __syncthreads();
+  // ---- sort the distinct pids (they are distinct: nothing to drop afterwards)
+  if (total > 1) {
+    if (P2 == 1024) bitonic_sort_regs<1, uint32_t, false>(keys, P2, tid);
+    else if (P2 == 2048) bitonic_sort_regs<2, uint32_t, false>(keys, P2, tid);
+    else if (P2 == 4096) bitonic_sort_regs<4, uint32_t, false>(keys, P2, tid);
+    else if (P2 == 8192) bitonic_sort_regs<8, uint32_t, false>(keys, P2, tid);
+    else bitonic_sort_regs<16, uint32_t, false>(keys, P2, tid);
+  }
+  for (int i = tid; i < n; i += nt) out_pids[(int64_t)q * n + i] = i < (int)total ? (int64_t)keys[i] : (int64_t)-1;
   if (tid == 0) out_count[q] = (int32_t)total;
 }
 

@@ -29,9 +29,18 @@ def load_doclens(directory, flatten=True):
     return all_doclens
 
 
-def load_index_part(filename):
-    """index_manager.py:12-18.  ``weights_only=True``: nothing in the file is executed."""
-    part = torch.load(filename, map_location="cpu", weights_only=True)
+def load_index_part(filename, mmap=False):
+    """index_manager.py:12-18.  ``weights_only=True``: nothing in the file is executed.  ``mmap``: map the file instead
+    of reading it (a shard loader that needs a slice of a part touches only those pages); files in torch's legacy
+    (non-zip) format cannot be mapped and are read whole."""
+    part = None
+    if mmap:
+        try:
+            part = torch.load(filename, map_location="cpu", weights_only=True, mmap=True)
+        except (RuntimeError, ValueError):
+            part = None
+    if part is None:
+        part = torch.load(filename, map_location="cpu", weights_only=True)
     if type(part) == list:  # backward compatibility branch of the reference
         part = torch.cat(part)
     return part

@@ -166,6 +166,16 @@ class ColbertRanker:
         self.d_offsets = self.doclens_pfxsum[:-1].contiguous().to(dev)
         self.n_docs = len(doclens)
         self._tls = threading.local()
+        # candidate-side glue: the doc of every 64th token row (maxsim_build_row_blocks; the reference's emb2pid,
+        # colbert_ranker.py:163-174, 64x smaller) -- what embedding_ids_to_pids looks token rows up in
+        self.d_row_blocks = None
+        if dev.type == "cuda":
+            nbytes = int(_lib.lib.maxsim_row_blocks_bytes(self.num_embeddings))
+            self.d_row_blocks = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                rc = _lib.lib.maxsim_build_row_blocks(_ptr(self.d_offsets), self.n_docs, self.num_embeddings,
+                                                      _ptr(self.d_row_blocks), _stream(dev))
+            _lib.check(rc, "maxsim_build_row_blocks")
         self.set_strides(reference_strides(self.doclens) if strides is None else strides)
 
     def set_strides(self, strides):
@@ -227,7 +237,8 @@ class ColbertRanker:
         qm = None
         if q_mask is not None:
             assert tuple(q_mask.shape) == (nq, Lq), (tuple(q_mask.shape), (nq, Lq))
-            qm = (q_mask.to(dev) != 0).to(torch.uint8).contiguous()            # q_word_mask.bool(), training_utils.py:50
+            qm = q_mask.to(dev)                                                # q_word_mask.bool(), training_utils.py:50
+            qm = (qm if qm.dtype == torch.bool else (qm != 0)).contiguous().view(torch.uint8)   # (a bool mask's bytes: no copy)
         scores = torch.empty(nq, ncand, dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             if cand_count is None:
@@ -273,22 +284,36 @@ class ColbertRanker:
         return self.topk(scores, cand_pids, k, cand_count)
 
     # ------------------------------------------------------------------------------------------
-    def embedding_ids_to_pids(self, embedding_ids, trim=True):
+    def embedding_ids_to_pids(self, embedding_ids, trim=True, keep=None, id_base=0):
         """GPU form of ``ColbertIndex.embedding_ids_to_pids`` (colbert_ranker.py:212-229): token rows returned by the
-        ANN search, ``[nq, Lq * faiss_depth]`` int64 (as reshaped at colbert_ranker.py:178), -> per-query DISTINCT pids,
-        ascending, padded with -1: a ``cand_pids`` matrix for ``rerank_batch`` -- no ``.tolist()`` / ``set()`` /
-        ``Pool(16)`` hop through the host.  Returns ``(cand [nq, width], counts [nq])``; ``trim`` cuts the width to the
-        largest count (one host sync)."""
+        ANN search, ``[nq, Lq * faiss_depth]`` int64 (as reshaped at colbert_ranker.py:178; or ``[nq, Lq, faiss_depth]``), ->
+        per-query DISTINCT pids, ascending, padded with -1: a ``cand_pids`` matrix for ``rerank_batch`` -- no ``.tolist()`` /
+        ``set()`` / ``Pool(16)`` hop through the host.  Returns ``(cand [nq, width], counts [nq])``; ``trim`` cuts the width
+        to the largest count (one host sync).
+        ``keep`` [nq, Lq] (0 = dropped): the neighbours of a dropped query token do not count (``keep_nonzero``,
+        training_utils.py:48-53) -- applied in the kernel, the ids are not rewritten.  ``id_base``: subtracted from every id;
+        ids outside ``[id_base, id_base + num_embeddings)`` are dropped (a doc shard passes the global row of its first
+        token)."""
         dev = self.device
+        if dev.type != "cuda":
+            raise RuntimeError("colbert_amd runs on the GPU only (libmaxsim has no CPU path)")
         e = embedding_ids.to(device=dev, dtype=torch.int64).contiguous()
-        assert e.dim() == 2
-        nq, n = e.shape
+        assert e.dim() in (2, 3)
+        nq = e.size(0)
+        n = e.numel() // max(nq, 1) if nq else (e.size(1) if e.dim() == 2 else e.size(1) * e.size(2))
+        km, per_tok = None, 1
+        if keep is not None:
+            km = keep.to(dev)
+            km = (km if km.dtype == torch.bool else (km != 0)).contiguous().view(torch.uint8)     # bool -> bytes: no copy
+            assert km.dim() == 2 and km.size(0) == nq and km.size(1) > 0 and n % km.size(1) == 0, (tuple(km.shape), n)
+            per_tok = n // km.size(1)
         out = torch.empty(nq, n, dtype=torch.int64, device=dev)
         cnt = torch.empty(nq, dtype=torch.int32, device=dev)
         with torch.cuda.device(dev):
-            rc = _lib.lib.maxsim_embedding_ids_to_pids(_ptr(e), nq, n, _ptr(self.d_offsets), self.n_docs,
-                                                       self.num_embeddings, _ptr(out), _ptr(cnt), _stream(dev))
-        _lib.check(rc, "maxsim_embedding_ids_to_pids")
+            rc = _lib.lib.maxsim_embedding_ids_to_pids_ex(_ptr(e), nq, n, per_tok, _ptr(km), int(id_base), _ptr(self.d_offsets),
+                                                          self.n_docs, self.num_embeddings, _ptr(self.d_row_blocks), _ptr(out),
+                                                          _ptr(cnt), _stream(dev))
+        _lib.check(rc, "maxsim_embedding_ids_to_pids_ex")
         if trim and nq > 0:
             out = out[:, :max(int(cnt.max().item()), 1)].contiguous()
         return out, cnt

@@ -83,19 +83,22 @@ def assert_strides_agree(strides, group=None, device=None):
     """Fails loudly when the ranks of a doc-sharded index do not bucket by the same strides (a shard built with
     ``sync_strides=False`` from its own percentiles, a rank that loaded another index): the 0-floor -- and therefore
     the scores -- would silently differ from the unsharded reference (colbert_ranker.py:90, :108-109).  One small
-    all_reduce(MAX) of (strides, -strides)."""
+    all_reduce(MAX) of (strides, -strides) that EVERY rank takes part in: a rank whose own list is malformed (more than
+    the reference's four strides, :36-40) sends a sentinel length instead of raising on its own, so that all ranks leave
+    the collective and all of them raise."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
     st = sorted(int(x) for x in strides)
-    if len(st) > 4:
-        raise ValueError(f"at most 4 distinct strides (colbert_ranker.py:36-40), got {st}")
-    v = torch.tensor([len(st)] + st + [0] * (4 - len(st)), dtype=torch.int64)
+    too_many = len(st) > 4
+    v = torch.tensor([5, 0, 0, 0, 0] if too_many else [len(st)] + st + [0] * (4 - len(st)), dtype=torch.int64)
     both = torch.cat([v, -v])
     if device is None and dist.get_backend(group) == "nccl":
         device = torch.device("cuda", torch.cuda.current_device())
     both = both.to(device) if device is not None else both
     dist.all_reduce(both, op=dist.ReduceOp.MAX, group=group)
     both = both.cpu()
+    if int(both[0]) > 4:
+        raise ValueError(f"at most 4 distinct strides (colbert_ranker.py:36-40); this rank has {st}")
     if not torch.equal(both[:5], -both[5:]):
         raise RuntimeError(f"doc shards disagree on the length-bucket strides: this rank has {st}, the ranks' maxima are "
                            f"{both[1:5].tolist()} and minima {(-both[6:]).tolist()} -- every shard must use the strides "
@@ -104,20 +107,22 @@ def assert_strides_agree(strides, group=None, device=None):
 
 def all_gather_topk(top_s, top_p, world, group=None):
     """The path's ONE exchange step: every rank's [nq, k] scores and global pids -> [world, nq, k] on every rank.
-    Scores travel as their bit patterns next to the pids in one int64 payload, so it is a single collective."""
+    One collective of 12 bytes per entry: per query k int64 pids as 2k int32 words, then the k fp32 scores
+    as their bit patterns."""
     nq, k = top_s.shape
     dev = top_s.device
-    payload = torch.empty(nq, 2 * k, dtype=torch.int64, device=dev)
-    payload[:, :k] = top_p
-    payload[:, k:] = top_s.contiguous().view(torch.int32)
+    payload = torch.empty(nq, 3 * k, dtype=torch.int32, device=dev)
+    payload[:, :2 * k] = top_p.contiguous().view(torch.int32)
+    payload[:, 2 * k:] = top_s.contiguous().view(torch.int32)
     if dev.type == "cuda" and dist.get_backend(group) == "gloo":
         # rehearsal on a one-GPU box (RCCL refuses two ranks on one device): stage through the host
         payload = payload.cpu()
-    g = torch.empty(world * nq, 2 * k, dtype=torch.int64, device=payload.device)
+    g = torch.empty(world * nq, 3 * k, dtype=torch.int32, device=payload.device)
     dist.all_gather_into_tensor(g, payload, group=group)
-    g = g.view(world, nq, 2 * k).to(dev)
-    gs = g[..., k:].to(torch.int32).view(torch.float32)
-    return gs, g[..., :k]
+    g = g.view(world, nq, 3 * k).to(dev)
+    gp = g[..., :2 * k].contiguous().view(torch.int64)
+    gs = g[..., 2 * k:].contiguous().view(torch.float32)
+    return gs, gp
 
 
 def merge_gathered(all_scores, all_pids, k, topk_fn):
@@ -129,27 +134,64 @@ def merge_gathered(all_scores, all_pids, k, topk_fn):
 
 
 class ShardedRanker:
-    def __init__(self, local_ranker, lo, hi, group=None, score_fn=None, topk_fn=None, sync_strides=True):
+    """One rank's view of a doc-sharded index: ``local_ranker`` holds the docs with global pids [lo, hi).
+
+    ``load_shard`` builds one straight from the reference's index files.  Built by hand (``ShardedRanker(local, lo, hi)``)
+    every rank must construct it at the same point: with more than one rank the constructor runs small collectives --
+    two all_reduces for the strides of the whole index (``sync_strides=True``) or none (``False``: the caller set them),
+    ONE all_reduce that checks that all ranks bucket alike (always, also with ``sync_strides=False``), and one all_gather
+    of (lo, docs, token rows) unless ``n_docs_total`` and ``tok_lo`` are both given.
+
+    n_docs_total : docs of the WHOLE index (``rank_forward``'s pid range check and negative-pid wrap, colbert_ranker.py:88)
+    tok_lo       : global token row of this shard's first token (``retrieve_batch`` takes GLOBAL token rows, as the ANN
+                   index over the whole collection returns them, colbert_ranker.py:176-181)
+    score_fn / topk_fn / pids_fn : injectable so that the partition / gather / merge logic runs on CPU ranks (``gloo``
+                   tests) with the oracle as scorer; the product default is the HIP path of the local ``ColbertRanker``
+    """
+
+    def __init__(self, local_ranker, lo, hi, group=None, score_fn=None, topk_fn=None, sync_strides=True, *,
+                 n_docs_total=None, tok_lo=None, pids_fn=None):
         self.local = local_ranker
         self.lo, self.hi = int(lo), int(hi)
         self.group = group
         self.score_fn = score_fn if score_fn is not None else local_ranker.score_candidates
         self.topk_fn = topk_fn if topk_fn is not None else local_ranker.topk
+        self.pids_fn = pids_fn        # None: the local ranker's embedding_ids_to_pids (keep-mask and id_base applied in the kernel)
         # the product scorer / top-k take the per-row live counts (counted rows: maxsim_rerank_counted / maxsim_topk_counted);
         # injected ones (CPU tests) get the plain signature unless they say otherwise
         self.score_counted = score_fn is None
         self.topk_counted = topk_fn is None
         self.force_exchange = False   # diagnostic: run the exchange + merge even at world size 1 (bench.py --force-dist)
         self.exchange_events = None   # diagnostic: a list here collects (start, stop) HIP events of every exchange + merge
-        # bucket by the strides of the whole index (see the module docstring); every rank must construct its
-        # ShardedRanker at the same point (two small all_reduces)
-        if hasattr(local_ranker, "set_strides") and self._world() > 1:
-            dev = local_ranker.device if local_ranker.device.type == "cuda" else None
+        world = self._world()
+        dev = None
+        if hasattr(local_ranker, "device") and local_ranker.device.type == "cuda":
+            dev = local_ranker.device
+        # bucket by the strides of the whole index (see the module docstring)
+        if hasattr(local_ranker, "set_strides") and world > 1:
             if sync_strides:
                 local_ranker.set_strides(global_strides(local_ranker.doclens, group, dev))
             # sync_strides=False (the caller set the strides itself) is still checked: ranks that bucket differently
             # would return scores that differ from the unsharded reference without any error
             assert_strides_agree(local_ranker.strides, group, dev)
+        self.n_docs_total = None if n_docs_total is None else int(n_docs_total)
+        self.tok_lo = None if tok_lo is None else int(tok_lo)
+        n_tok_local = getattr(local_ranker, "num_embeddings", None)
+        if world == 1:
+            self.n_docs_total = self.hi if self.n_docs_total is None else self.n_docs_total
+            self.tok_lo = 0 if (self.tok_lo is None and self.lo == 0) else self.tok_lo
+        elif (self.n_docs_total is None or self.tok_lo is None) and n_tok_local is not None:
+            # where the shards sit in the whole index: every rank's (lo, docs, token rows)
+            mine = torch.tensor([self.lo, self.hi - self.lo, int(n_tok_local)], dtype=torch.int64)
+            mine = mine.to(dev) if (dev is not None and dist.get_backend(group) == "nccl") else mine
+            rows = torch.empty(world * 3, dtype=torch.int64, device=mine.device)
+            dist.all_gather_into_tensor(rows, mine, group=group)
+            rows = rows.view(world, 3).cpu()
+            if self.n_docs_total is None:
+                self.n_docs_total = int((rows[:, 0] + rows[:, 1]).max().item())
+            if self.tok_lo is None:
+                self.tok_lo = int(rows[rows[:, 0] < self.lo, 2].sum().item())
+        self.tok_hi = None if (self.tok_lo is None or n_tok_local is None) else self.tok_lo + int(n_tok_local)
 
     def local_topk(self, Q, cand_global, depth, q_len=None, q_mask=None):
         """Scores this shard's share of every query's GLOBAL candidate list and returns its local top-k with global pids:
@@ -190,6 +232,133 @@ class ShardedRanker:
         caller's stream wait for the merge and returns (pids, scores).  Collectives are issued in call order on every
         rank, so handles must be created in the same order everywhere."""
         return _Exchange(self, top_p, top_s, int(depth))
+
+
+    # ------------------------------------------------------------------------------------------
+    def local_retrieve_topk(self, Q, keep, embedding_ids, k):
+        """This shard's leg of ``retrieve_batch``: GLOBAL token rows [bs, n] (-1 = dropped) -> the rows inside this shard's
+        token range as local rows -> distinct local pids (counted rows) -> counted rerank with ``keep`` as the per-token
+        predicate -> counted local top-k with GLOBAL pids; (pids [bs,k], scores [bs,k]), (-1, -inf) behind a short row."""
+        if self.tok_lo is None or self.tok_hi is None:
+            raise ValueError("retrieve_batch needs tok_lo (the global token row of this shard's first token)")
+        if self.pids_fn is None:        # colbert_ranker.py:212-229 on this shard's rows: the kernel drops foreign rows
+            cand, counts = self.local.embedding_ids_to_pids(embedding_ids, trim=False, keep=keep, id_base=self.tok_lo)
+        else:                           # injected (CPU ranks): local rows, -1 for foreign rows and dropped tokens' neighbours
+            ids = embedding_ids.reshape(embedding_ids.size(0), keep.size(1), -1).masked_fill(~keep.unsqueeze(-1), -1)
+            ids = ids.reshape(embedding_ids.size(0), -1)
+            inside = (ids >= self.tok_lo) & (ids < self.tok_hi)
+            cand, counts = self.pids_fn(torch.where(inside, ids - self.tok_lo, torch.full_like(ids, -1)))
+        kw = {"q_mask": keep}
+        if self.score_counted:
+            kw["cand_count"] = counts
+        scores = self.score_fn(Q, cand, **kw)
+        top_p, top_s = self.topk_fn(scores, cand, k, counts) if self.topk_counted else self.topk_fn(scores, cand, k)
+        return torch.where(top_p >= 0, top_p + self.lo, top_p), top_s
+
+    def retrieve_batch(self, Q, q_active_padding, topk, embedding_ids=None, ann_search=None, faiss_depth=None):
+        """The batched driver (``colbert_amd.retrieve_batch``; reference: dense_server_client.py:44-48 +
+        faiss_indexers.py:224-235 + colbert_ranker.py:176-181, :212-229) on the doc-sharded index.  Every rank passes the
+        same Q [bs, Lq, h], q_active_padding [bs, Lq] and the same ANN result: GLOBAL token rows of the whole collection
+        (``embedding_ids`` [bs, Lq, faiss_depth], or ``ann_search``).  Each rank keeps the rows inside its token range,
+        reranks its distinct docs and takes a local top-k; ONE all_gather; every rank merges and returns the reference's
+        per-query ``(pids, scores)`` lists -- equal on every rank, equal to the unsharded driver's."""
+        from .retriever import prepare_embedding_ids, unpack_topk_lists
+        dev = self.local.device
+        Q = Q.to(dev)
+        keep, ids = prepare_embedding_ids(dev, Q, q_active_padding, embedding_ids, ann_search, faiss_depth, mask_ids=False)
+        bs = Q.size(0)
+        ids = ids.reshape(bs, -1)
+        k = min(int(topk), ids.size(1))
+        top_p, top_s = self.local_retrieve_topk(Q, keep, ids, k)
+        world = self._world()
+        if world > 1 or (self.force_exchange and dist.is_initialized()):
+            gs, gp = all_gather_topk(top_s, top_p, world, self.group)
+            top_p, top_s = merge_gathered(gs, gp, k, self.topk_fn)
+        return unpack_topk_lists(top_p, top_s, (top_p >= 0).sum(1, dtype=torch.int32))
+
+    def rank_forward(self, Q, pids, views=None, depth=10, output_D_embedding=False):
+        """``ColbertRanker.rank_forward`` (colbert_ranker.py:75-137) on the doc-sharded index: Q [1, h, Lq] (dim-major, as
+        faiss_indexers.py:232-233 hands it over), ``pids`` a list or tensor of GLOBAL pids, the same on every rank ->
+        ``(pids, scores)`` lists sorted by score descending, at most ``depth`` long, on every rank."""
+        assert len(pids) > 0                                                  # :76
+        assert Q.size(0) in [1, len(pids)]                                    # :77
+        if Q.size(0) != 1:
+            raise NotImplementedError("rank_forward with one query per candidate is not exercised by the reference")
+        if output_D_embedding:
+            raise NotImplementedError("output_D_embedding on a doc-sharded index: the top docs' rows live on other ranks; "
+                                      "use the single-GPU ColbertRanker")
+        dev = self.local.device
+        n_total = self.n_docs_total
+        pids_t = (torch.tensor(pids, dtype=torch.int64) if type(pids) is list else pids.to(torch.int64)).view(1, -1)
+        lo, hi = (int(x) for x in torch.aminmax(pids_t))
+        if hi >= n_total or lo < -n_total:                                     # `self.doclens[pids]`, :88
+            raise IndexError(f"index {hi if hi >= n_total else lo} is out of bounds for dimension 0 with size {n_total}")
+        pids_t = pids_t.to(dev)
+        cand = torch.where(pids_t < 0, pids_t + n_total, pids_t) if lo < 0 else pids_t   # torch indexing wraps, :88
+        Qt = Q.permute(0, 2, 1)                                               # :111 -> [1, Lq, h]
+        top_p, top_s = self.rerank_batch(Qt, cand, depth=min(int(depth), cand.size(1)))
+        out_p, out_s = top_p[0].tolist(), top_s[0].tolist()
+        if lo < 0:
+            # :129 returns the caller's own values (`pids[order]`): hand every wrapped pid back as it was passed in
+            # (a doc listed twice, as p and p - N, has one score; which of the two spellings comes first is a tie)
+            back = {}
+            for orig, c in zip(pids_t[0].tolist(), cand[0].tolist()):
+                back.setdefault(c, []).append(orig)
+            out_p = [back[c].pop(0) for c in out_p]
+        return out_p, out_s
+
+
+def load_shard(index_path, rank=None, world=None, device="cuda", index_dtype=torch.float16, group=None, fp32_mode="exact",
+               dim=None, model=None, score_fn=None, topk_fn=None, pids_fn=None):
+    """Rank ``rank``'s shard of a reference-built index, straight from its files (``{i}.pt`` + ``doclens.{i}.json``:
+    loaders.py:7-32, index_manager.py:12-18, colbert_ranker.py:61-73) -> ``ShardedRanker``.
+
+    Every rank reads ALL ``doclens.{i}.json`` (small) and derives, with no collective: its contiguous pid range
+    (``shard_range``), the global token row of its first token, and the length-bucket strides of the WHOLE index
+    (colbert_ranker.py:36-40; the 0-floor of :90, :108-109 depends on them).  Only the part files that overlap the
+    shard's token range are opened, memory-mapped, and only the overlapping rows are copied to HBM -- a part that
+    straddles a shard boundary is sliced.  ``rank`` / ``world`` default to the process group's; given explicitly they
+    also work without one (one process loading shard after shard).  The constructor's stride cross-check (one
+    all_reduce) still runs when a process group with more than one rank exists."""
+    from .ranker import ColbertRanker, reference_strides
+    from . import index_io
+    if rank is None or world is None:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise ValueError("load_shard: give rank and world, or initialise torch.distributed first")
+        rank = dist.get_rank(group) if rank is None else rank
+        world = dist.get_world_size(group) if world is None else world
+    _, parts_paths, _ = index_io.get_parts(index_path)                        # colbert_ranker.py:18
+    parts_doclens = index_io.load_doclens(index_path, flatten=False)          # :22
+    doclens = [int(x) for y in parts_doclens for x in y]
+    n_total = len(doclens)
+    lo, hi = shard_range(n_total, rank, world)
+    if hi <= lo:
+        raise ValueError(f"shard {rank} of {world} is empty: the index has only {n_total} docs")
+    strides = reference_strides(torch.tensor(doclens, dtype=torch.int64))    # of the WHOLE index
+    tok_lo = sum(doclens[:lo])
+    # walk the parts: docs [d0, d1) and token rows [t0, t1) of each; keep the overlap with [lo, hi)
+    local_doclens, slices = [], []
+    d0 = t0 = 0
+    for path, dl in zip(parts_paths, parts_doclens):
+        d1, t1 = d0 + len(dl), t0 + sum(int(x) for x in dl)
+        a, b = max(lo, d0), min(hi, d1)
+        if a < b:
+            sub = [int(x) for x in dl[a - d0:b - d0]]
+            r0 = sum(int(x) for x in dl[:a - d0])
+            local_doclens.append(sub)
+            slices.append((path, r0, r0 + sum(sub), t1 - t0))
+        d0, t0 = d1, t1
+
+    def rows():
+        for path, r0, r1, n_rows in slices:
+            part = index_io.load_index_part(path, mmap=True)
+            assert part.size(0) == n_rows, (path, part.size(0), n_rows)       # colbert_ranker.py:69-70's size agreement
+            yield part[r0:r1]
+            del part
+    local = ColbertRanker(parts=rows(), parts_doclens=local_doclens, dim=dim, model=model, device=device,
+                          index_dtype=index_dtype, fp32_mode=fp32_mode, strides=strides)
+    return ShardedRanker(local, lo, hi, group=group, score_fn=score_fn, topk_fn=topk_fn, pids_fn=pids_fn,
+                         sync_strides=False, n_docs_total=n_total, tok_lo=tok_lo)
 
 
 class _Exchange:

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define MAXSIM_VERSION 121 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
+#define MAXSIM_VERSION 122 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
                               maxsim_shard_candidates, maxsim_build_doc_table; 111: maxsim_score_dense_kernel;
                               120: counted candidate rows (maxsim_rerank_counted, maxsim_topk_counted);
                               121: maxsim_index_view.uniform_len, read-ceiling probes, maxsim_host_alloc_coherent */
@@ -179,6 +179,26 @@ int maxsim_topk(const float* scores, const int64_t* pids, int nq, int ncand, int
  */
 int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const int64_t* tok_offsets, int64_t n_docs,
                                  int64_t n_tokens, int64_t* out_pids, int32_t* out_count, void* stream);
+
+/*
+ * The same step with the driver's two elementwise passes folded in and a faster row -> pid lookup:
+ *   ids_per_token, tok_keep [nq, n / ids_per_token] uint8 or NULL : slot i of a query holds a neighbour of its token
+ *               i / ids_per_token (the layout of colbert_ranker.py:178); the neighbours of a token with tok_keep == 0 are
+ *               ignored -- the query tokens keep_nonzero drops before the search (training_utils.py:48-53,
+ *               dense_server_client.py:45).  n must be a multiple of ids_per_token when tok_keep is given.
+ *   id_base   : subtracted from every id first; ids outside [id_base, id_base + n_tokens) are dropped.  A doc shard passes
+ *               the global token row of its first token and gets LOCAL pids of the rows that are its own.
+ *   row_blocks: NULL, or the table maxsim_build_row_blocks wrote for this (tok_offsets, n_docs, n_tokens): the doc of
+ *               every 64th token row, 4 bytes each (the reference keeps 4 bytes for EVERY row: emb2pid,
+ *               colbert_ranker.py:163-174).  With it a lookup is ~3 loads instead of a ~log2(n_docs)-step binary search.
+ * Same output contract as maxsim_embedding_ids_to_pids.
+ */
+int maxsim_embedding_ids_to_pids_ex(const int64_t* emb_ids, int nq, int n, int ids_per_token, const uint8_t* tok_keep,
+                                    int64_t id_base, const int64_t* tok_offsets, int64_t n_docs, int64_t n_tokens,
+                                    const void* row_blocks, int64_t* out_pids, int32_t* out_count, void* stream);
+/* Bytes of the row-block table of an index with n_tokens rows; its builder (one launch at index load time). */
+int64_t maxsim_row_blocks_bytes(int64_t n_tokens);
+int maxsim_build_row_blocks(const int64_t* tok_offsets, int64_t n_docs, int64_t n_tokens, void* row_blocks, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Index view: everything the rerank entry points need to know about one HBM-resident (shard of an) index, passed as

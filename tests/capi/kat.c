@@ -197,6 +197,36 @@ int main(void) {
     CHECK(rc == MAXSIM_OK && rc2 == MAXSIM_OK && rc3 == MAXSIM_OK && rc4 == MAXSIM_OK && wlb > 0, "counted rows: return codes");
     CHECK(memcmp(s6, s6c, 24) == 0 && isinf(s6c[4]) && isinf(s6c[5]) && s6c[0] == 1.5f, "rerank_counted == rerank_ex (incl. the -inf tail)");
     CHECK(memcmp(ts3, ts3c, 12) == 0 && memcmp(tp3, tp3c, 24) == 0 && tp3c[0] == 12, "topk_counted == topk");
+
+    /* ANN token rows -> distinct pids (colbert_ranker.py:212-229) through the row-block table, with a dropped query token
+       and a shard's id_base: three docs of 2, 0, 3 rows (tok_offsets 0 2 2); 2 query tokens x 3 neighbours each */
+    const int64_t offs3[3] = {0, 2, 2};
+    const int64_t ids6[6] = {104, 100, -1, 101, 103, 999};   /* id_base 100 -> rows 4 0 . | 1 3 (999: another shard) */
+    const uint8_t keep2[2] = {1, 1}, keep1[2] = {0, 1};
+    void *doffs3 = to_dev(offs3, sizeof offs3), *dids6 = to_dev(ids6, sizeof ids6);
+    void *dkeep2 = to_dev(keep2, 2), *dkeep1 = to_dev(keep1, 2);
+    const int64_t rbb = maxsim_row_blocks_bytes(5);
+    void* drb = NULL;
+    int64_t* dout6 = NULL;
+    int32_t* dn6 = NULL;
+    hipMalloc(&drb, (size_t)rbb); hipMalloc((void**)&dout6, 48); hipMalloc((void**)&dn6, 4);
+    rc = maxsim_build_row_blocks((const int64_t*)doffs3, 3, 5, drb, NULL);
+    rc2 = maxsim_embedding_ids_to_pids_ex((const int64_t*)dids6, 1, 6, 3, (const uint8_t*)dkeep2, 100, (const int64_t*)doffs3, 3, 5,
+                                          drb, dout6, dn6, NULL);
+    int64_t out6[6];
+    int32_t n6 = -1;
+    hipDeviceSynchronize();
+    hipMemcpy(out6, dout6, 48, hipMemcpyDeviceToHost); hipMemcpy(&n6, dn6, 4, hipMemcpyDeviceToHost);
+    CHECK(rc == MAXSIM_OK && rc2 == MAXSIM_OK && rbb == 8 && n6 == 2 && out6[0] == 0 && out6[1] == 2 && out6[2] == -1 && out6[5] == -1,
+          "embedding_ids_to_pids_ex: row blocks + id_base (the empty doc 1 owns no row)");
+    rc2 = maxsim_embedding_ids_to_pids_ex((const int64_t*)dids6, 1, 6, 3, (const uint8_t*)dkeep1, 100, (const int64_t*)doffs3, 3, 5,
+                                          NULL, dout6, dn6, NULL);
+    hipDeviceSynchronize();
+    hipMemcpy(out6, dout6, 48, hipMemcpyDeviceToHost); hipMemcpy(&n6, dn6, 4, hipMemcpyDeviceToHost);
+    CHECK(rc2 == MAXSIM_OK && n6 == 2 && out6[0] == 0 && out6[1] == 2 && out6[2] == -1,
+          "embedding_ids_to_pids_ex: first query token dropped, no table (rows 1 and 3 -> docs 0 and 2)");
+    CHECK(maxsim_embedding_ids_to_pids_ex((const int64_t*)dids6, 1, 6, 4, (const uint8_t*)dkeep2, 0, (const int64_t*)doffs3, 3, 5,
+                                          NULL, dout6, dn6, NULL) == MAXSIM_EINVAL, "ids_per_token must divide n -> EINVAL");
   }
   printf("%s\n", failures ? "FAILED" : "ALL OK");
   return failures ? 1 : 0;

@@ -481,7 +481,8 @@ def test_stride_sync_collectives_run_on_rccl(ca, monkeypatch):
         sharded.assert_strides_agree(gs)                                      # all_reduce(MAX) of (strides, -strides)
         emb = nrm(gen, int(doclens.sum()), 128).half()
         r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens.tolist()], dim=128)
-        sr = sharded.ShardedRanker(r, 0, 500)                                 # the shipped constructor: both, then set_strides
+        # the shipped constructor: both, then set_strides (placement given: its all_gather needs the real world size)
+        sr = sharded.ShardedRanker(r, 0, 500, n_docs_total=500, tok_lo=0)
         assert r.strides == gs and sr._world() == 2
     finally:
         monkeypatch.undo()
