@@ -20,7 +20,7 @@ SYMBOLS = ("maxsim_version", "maxsim_strerror", "maxsim_score_dense", "maxsim_re
            "maxsim_build_doc_table", "maxsim_shard_candidates", "maxsim_score_dense_kernel", "maxsim_worklist_bytes",
            "maxsim_rerank_counted", "maxsim_topk_counted", "maxsim_hbm_read_probe", "maxsim_hbm_read_probe_scattered",
            "maxsim_host_alloc_coherent", "maxsim_host_free", "maxsim_embedding_ids_to_pids_ex", "maxsim_row_blocks_bytes",
-           "maxsim_build_row_blocks")
+           "maxsim_build_row_blocks", "maxsim_index_view_bytes")
 
 
 class IndexView(ctypes.Structure):
@@ -28,7 +28,7 @@ class IndexView(ctypes.Structure):
     _fields_ = [("index", ctypes.c_void_p), ("index_dtype", ctypes.c_int32), ("h", ctypes.c_int32),
                 ("n_tokens", ctypes.c_int64), ("tok_offsets", ctypes.c_void_p), ("doclens", ctypes.c_void_p),
                 ("pad_len", ctypes.c_void_p), ("n_docs", ctypes.c_int64), ("doc_table", ctypes.c_void_p),
-                ("uniform_len", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("uniform_len", ctypes.c_int32), ("struct_size", ctypes.c_int32)]
 
 
 class MaxSimError(RuntimeError):
@@ -96,6 +96,11 @@ def _load():
     lib.maxsim_embedding_ids_to_pids.argtypes = [vp, i32, i32, vp, i64, i64, vp, vp, vp]
     lib.maxsim_embedding_ids_to_pids_ex.restype = i32
     lib.maxsim_embedding_ids_to_pids_ex.argtypes = [vp, i32, i32, i32, vp, i64, vp, i64, i64, vp, vp, vp, vp]
+    lib.maxsim_index_view_bytes.restype = i64
+    lib.maxsim_index_view_bytes.argtypes = []
+    if lib.maxsim_index_view_bytes() != ctypes.sizeof(IndexView):
+        raise ImportError(f"{LIB_PATH}: maxsim_index_view is {lib.maxsim_index_view_bytes()} bytes in the library, "
+                          f"{ctypes.sizeof(IndexView)} in this binding -- rebuild (colbert_amd/csrc/build.sh)")
     lib.maxsim_row_blocks_bytes.restype = i64
     lib.maxsim_row_blocks_bytes.argtypes = [i64]
     lib.maxsim_build_row_blocks.restype = i32

@@ -72,6 +72,7 @@ int launch_generic(Params& p, int dt, hipStream_t st) {
 extern "C" {
 
 int maxsim_version(void) { return MAXSIM_VERSION; }
+int64_t maxsim_index_view_bytes(void) { return (int64_t)sizeof(maxsim_index_view); }
 
 const char* maxsim_strerror(int code) {
   switch (code) {
@@ -280,7 +281,10 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
     hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, list_slots, wl);
     hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
     if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
-    const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * LIST_MIN_ITEMS + nq;
+    // k_worklist_scan may settle on any docs-per-item in [D0 / 2, 2 D0] (and keeps halving while the launch is below its
+    // minimum): the grid is sized for the SMALLEST it can pick, so that no workgroup runs two items while CU slots idle
+    const int Dlow = D0 / 2 > 1 ? D0 / 2 : 1;
+    const int64_t by_rows = (int64_t)nq * ((ncand + Dlow - 1) / Dlow), small = 2 * LIST_MIN_ITEMS + nq;
     const int64_t max_items = by_rows > small ? by_rows : small;
     return for_query_slices(p, [&] { return launch_stream_list(p, index_dtype, max_items, st); });
   }
@@ -306,7 +310,8 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
                          MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) >= 0 ? MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) : 256, wl);  // (one workgroup per CU is resident)
       hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
       if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
-      const int64_t by_rows = (int64_t)nq * ((ncand + D0 - 1) / D0), small = 2 * 256 + nq;
+      const int Dlow = D0 / 2 > 1 ? D0 / 2 : 1;   // (the smallest docs-per-item the scan can settle on, as above)
+      const int64_t by_rows = (int64_t)nq * ((ncand + Dlow - 1) / Dlow), small = 2 * 256 + nq;
       const int64_t max_items = by_rows > small ? by_rows : small;
       int rc = for_query_slices(p, [&] { return launch_bigh_rerank_list(p, dt, max_items, st); });
       if (rc != MAXSIM_ERANGE) return rc;
@@ -341,7 +346,7 @@ int maxsim_rerank(const void* index, int index_dtype, int64_t n_tokens, const in
 int maxsim_rerank_ex(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
                      const uint8_t* q_mask, const int64_t* cand_pids, int nq, int ncand, int Lq, float* scores,
                      void* stream) {
-  if (!iv) return MAXSIM_EINVAL;
+  if (!iv || (iv->struct_size != 0 && iv->struct_size != (int32_t)sizeof(maxsim_index_view))) return MAXSIM_EINVAL;
   return rerank_impl(*iv, Q, q_dtype, q_len, q_mask, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream);
 }
 
@@ -352,7 +357,7 @@ void maxsim_diag_set_stamp_buffer(const void* p) { g_stamp_buffer = p; }
 int maxsim_rerank_counted(const maxsim_index_view* iv, const void* Q, int q_dtype, const int32_t* q_len,
                           const uint8_t* q_mask, const int64_t* cand_pids, const int32_t* cand_count, int nq, int ncand,
                           int Lq, float* scores, void* worklist, int64_t worklist_bytes, void* stream) {
-  if (!iv) return MAXSIM_EINVAL;
+  if (!iv || (iv->struct_size != 0 && iv->struct_size != (int32_t)sizeof(maxsim_index_view))) return MAXSIM_EINVAL;
   return rerank_impl(*iv, Q, q_dtype, q_len, q_mask, cand_pids, nq, ncand, Lq, scores, (hipStream_t)stream, cand_count,
                      worklist, worklist_bytes);
 }
@@ -429,7 +434,7 @@ int64_t maxsim_rank_forward_workspace_bytes(int n) { return n > 0 ? (int64_t)n *
 int maxsim_rank_forward(const maxsim_index_view* iv, const void* Q, int q_dtype, int Lq, const int64_t* pids, int n,
                         int depth, void* workspace, int64_t* out_pids, float* out_scores, uint32_t* done_flag,
                         int sync, void* stream) {
-  if (!iv || n < 0 || depth < 1) return MAXSIM_EINVAL;
+  if (!iv || n < 0 || depth < 1 || (iv->struct_size != 0 && iv->struct_size != (int32_t)sizeof(maxsim_index_view))) return MAXSIM_EINVAL;
   if (n == 0) return MAXSIM_EEMPTY;  // assert len(pids) > 0, colbert_ranker.py:76
   if (n > 16384) return MAXSIM_ERANGE;
   if (!workspace || ((uintptr_t)workspace & 15) != 0 || !out_pids || !out_scores) return MAXSIM_EINVAL;

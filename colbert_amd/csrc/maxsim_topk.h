@@ -83,6 +83,7 @@ __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ sc
   const int n16 = (ncand + 15) & ~15;
   for (int i = tid; i < n16; i += 256)
     keys[i] = i < ncand ? (((uint64_t)orderable(srow[i]) << 32) | (uint32_t)(~(uint32_t)i)) : 0ull;  // 0 < every real key
+  if (n16 == 0 && tid == 0) keys[0] = 0ull;  // an empty counted row: topk_rank_group reads (and ignores) keys[0]
   __syncthreads();
   const int64_t* const pid_row = pids ? pids + (int64_t)q * row_w : nullptr;
   if (done_flag)  // the host may read the outputs while the kernel is still running: system-scope write-through

@@ -211,7 +211,8 @@ class ColbertRanker:
         lo, hi = int(self.doclens.min().item()), int(self.doclens.max().item())
         uniform = lo if (lo == hi and lo > 0 and lo in self.strides) else 0    # lo in strides: pad_len == doclen
         return _lib.IndexView(_ptr(self.tensor), idt, self.dim, self.num_embeddings, _ptr(self.d_offsets),
-                              _ptr(self.d_doclens), _ptr(self.d_pad_len), self.n_docs, _ptr(self.d_doc_table), uniform, 0)
+                              _ptr(self.d_doclens), _ptr(self.d_pad_len), self.n_docs, _ptr(self.d_doc_table), uniform,
+                              ctypes.sizeof(_lib.IndexView))
 
     # ------------------------------------------------------------------------------------------
     def score_candidates(self, Q, cand_pids, q_len=None, q_mask=None, cand_count=None):

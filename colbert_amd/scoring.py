@@ -21,11 +21,6 @@ def _ptr(t):
     return None if t is None else t.data_ptr()
 
 
-def _has_weights(mask):
-    """True when a floating-point mask holds anything but 0 and 1 (one small reduction; integer / bool masks never ask)."""
-    return bool(((mask != 0) & (mask != 1)).any().item())
-
-
 def _prepare(Q, D, q_mask, d_mask):
     if Q.dim() != 3 or D.dim() != 3 or q_mask.dim() != 2 or d_mask.dim() != 2:
         raise ValueError("score expects Q[q,m,h], D[d,n,h], q_mask[q,m], d_mask[d,n]")
@@ -39,10 +34,13 @@ def _prepare(Q, D, q_mask, d_mask):
     dev = Q.device
     out_dtype = torch.promote_types(torch.promote_types(Q.dtype, q_mask.dtype), torch.promote_types(D.dtype, d_mask.dtype))
     cdt = Q.dtype if Q.dtype == D.dtype and Q.dtype in _DT else torch.float32
-    if cdt != torch.float32 and q_mask.dtype.is_floating_point and _has_weights(q_mask):
-        # a floating-point q_mask that is not 0/1 (token WEIGHTS: allowed by the interface, never built by the reference,
-        # tokenizers.py:36,57): the 16-bit kernels fold Q * q_mask into a 16-bit query image, where the reference's product is
-        # exact in the promoted type (BaseModel.py:42) -- up to 3e-3 on a bf16 score.  Such calls compute from fp32 copies.
+    if cdt != torch.float32 and (q_mask.dtype.is_floating_point or d_mask.dtype.is_floating_point):
+        # a floating-point mask may hold token WEIGHTS (allowed by the interface, never built by the reference: its masks are
+        # int64 0/1, tokenizers.py:36,39,57).  The 16-bit kernels fold Q * q_mask into a 16-bit query image and apply d_mask to
+        # finished similarities, where the reference's products are exact in the promoted type (BaseModel.py:41-42) -- up to
+        # 3e-3 on a bf16 score -- so 16-bit operands with ANY floating-point mask compute from fp32 copies.  The rule looks at
+        # dtypes only: no reduction over the mask, no device-to-host sync in the training step's stream (integer / bool masks,
+        # the reference's, keep the 16-bit GEMM path).
         cdt = torch.float32
     Qc = Q.detach().to(device=dev, dtype=cdt).contiguous()
     Dc = D.detach().to(device=dev, dtype=cdt).contiguous()

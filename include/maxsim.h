@@ -223,8 +223,15 @@ typedef struct maxsim_index_view {
                                  host; for h == 128, an fp32 index and L in {4, 8, 16} the rerank then runs a kernel
                                  with the doc length compiled in, which does not consult the per-doc arrays at all
                                  (bit-identical scores, ~10 % faster). */
-  int32_t reserved;           /* 0 */
+  int32_t struct_size;        /* 0, or sizeof(maxsim_index_view) as the CALLER compiled it: the library refuses a size it
+                                 does not know (MAXSIM_EINVAL) instead of reading fields the caller's struct does not
+                                 have.  (The field sits where `reserved` (0) was up to version 121.  A caller built
+                                 against a header older than 120 has a shorter struct and no such field: compare
+                                 maxsim_version() with the MAXSIM_VERSION it was compiled with, or
+                                 maxsim_index_view_bytes() with its sizeof, at start-up.) */
 } maxsim_index_view;
+/* sizeof(maxsim_index_view) in THIS build of the library. */
+int64_t maxsim_index_view_bytes(void);
 
 /* Bytes of the packed descriptor table of n_docs docs (16 per doc). */
 int64_t maxsim_doc_table_bytes(int64_t n_docs);
@@ -295,10 +302,13 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
  * maxsim_rerank_counted: the device builds a dense list of work items from the counts (two small kernels: a scan and a
  *   fill, which also writes the -inf tail of `scores`) and the streaming kernel runs as a fixed grid that walks that list
  *   -- no host synchronisation to size the launch, no all-padding workgroups, every wave of every workgroup busy.  One
- *   rank's share of an 8-way sharded step then costs what the same docs cost as dense rows.  Served: h == 128 with docs
- *   longer than 24 tokens on average (any index dtype; wave-sized items) or a uniform 4 / 8 / 16-token fp32 index
- *   (uniform_len); 128 < h <= 1024 in multiples of 128 (workgroup-sized items: the waves share the staged query).
- *   Other shapes take maxsim_rerank_ex's path.
+ *   rank's share of an 8-way sharded step then costs what the same docs cost as dense rows.  Served (what rerank_impl
+ *   dispatches, maxsim.hip): every h == 128 index with 16-byte-aligned rows and Lq <= 32 per query slice, whatever its
+ *   doc lengths and index dtype (wave-sized items; a uniform 4 / 8 / 16-token fp32 index (uniform_len) runs the
+ *   fixed-length kernel's list form); 16 <= h <= 1024 with 16-byte-aligned rows, h != 128, whenever the query image and
+ *   at least 4 one-sub-tile rings fit the 160 KiB of LDS (workgroup-sized items: the waves share the staged query) --
+ *   including widths with a partial last 128-dim block (96, 192, 320 ...).  Other shapes (unaligned rows, h < 16,
+ *   h > 1024) take maxsim_rerank_ex's path.
  *   worklist: 16-byte aligned device scratch of maxsim_worklist_bytes(nq, ncand) bytes (contents need not survive the
  *   call; NULL or too small = maxsim_rerank_ex's path).  ncand < 2^20 for the list form.
  * maxsim_topk_counted: maxsim_topk that ranks the live slots only (rows longer than 2048: sorted as the next power of

@@ -225,6 +225,15 @@ int main(void) {
     hipMemcpy(out6, dout6, 48, hipMemcpyDeviceToHost); hipMemcpy(&n6, dn6, 4, hipMemcpyDeviceToHost);
     CHECK(rc2 == MAXSIM_OK && n6 == 2 && out6[0] == 0 && out6[1] == 2 && out6[2] == -1,
           "embedding_ids_to_pids_ex: first query token dropped, no table (rows 1 and 3 -> docs 0 and 2)");
+    /* the struct-size guard of maxsim_index_view: this build's size is accepted (as is 0), anything else is refused */
+    maxsim_index_view iv2 = iv;
+    iv2.struct_size = (int32_t)sizeof(maxsim_index_view);
+    rc = maxsim_rerank_ex(&iv2, dQ, MAXSIM_F32, NULL, NULL, dl, 1, 6, LQ, ds6, NULL);
+    iv2.struct_size = (int32_t)sizeof(maxsim_index_view) - 8;
+    rc2 = maxsim_rerank_ex(&iv2, dQ, MAXSIM_F32, NULL, NULL, dl, 1, 6, LQ, ds6, NULL);
+    hipDeviceSynchronize();
+    CHECK(rc == MAXSIM_OK && rc2 == MAXSIM_EINVAL && maxsim_index_view_bytes() == (int64_t)sizeof(maxsim_index_view),
+          "index view: struct_size guard");
     CHECK(maxsim_embedding_ids_to_pids_ex((const int64_t*)dids6, 1, 6, 4, (const uint8_t*)dkeep2, 0, (const int64_t*)doffs3, 3, 5,
                                           NULL, dout6, dn6, NULL) == MAXSIM_EINVAL, "ids_per_token must divide n -> EINVAL");
   }

@@ -370,7 +370,9 @@ def test_misaligned_operands_take_the_generic_path(ca):
 # top-k: colbert_ranker.py:128-130
 # ------------------------------------------------------------------------------------------------------
 @pytest.mark.parametrize("ncand,k", [(1, 1), (7, 3), (1000, 100), (1000, 10), (1024, 1024), (1025, 5), (16384, 100),
-                                      (5, 9)])
+                                      (5, 9),
+                                      # every size of the register sort network against torch (2 / 4 / 8 keys per thread)
+                                      (2049, 5), (3000, 100), (5000, 3000), (8192, 10)])
 def test_topk_vs_torch(ca, ncand, k):
     gen = torch.Generator().manual_seed(ncand + k)
     nq = 3
@@ -389,6 +391,29 @@ def test_topk_vs_torch(ca, ncand, k):
         assert bool((ts.cpu()[:, ncand:] == float("-inf")).all()) and bool((tp.cpu()[:, ncand:] == -1).all())
     tp2, _ = r.topk(s.cuda(), None, kk)
     assert torch.equal(tp2.cpu(), ei[:, :kk])
+
+
+@pytest.mark.parametrize("width,count", [(5000, 1500), (5000, 2048), (16384, 1025), (16384, 3000), (9000, 5000)])
+def test_counted_topk_vs_torch(ca, width, count):
+    """Counted rows against torch on the live prefix (not against the uncounted kernel): a row wider than 2048 whose count
+    lands in (1024, 2048] is sorted as 2048 keys (2 per thread), 3000 as 4096, 5000 as 8192."""
+    gen = torch.Generator().manual_seed(width + count)
+    nq, k = 3, 100
+    s = torch.randn(nq, width, generator=gen)
+    s[0, : count // 2] = s[0, count // 2: 2 * (count // 2)]                 # ties inside the live part
+    pids = torch.randint(0, 10 ** 12, (nq, width), generator=gen)
+    counts = torch.tensor([count, count - 1, 1], dtype=torch.int32)
+    for q in range(nq):
+        s[q, int(counts[q]):] = float("-inf")
+        pids[q, int(counts[q]):] = -1
+    r = ca.ColbertRanker(parts=[torch.zeros(4, 8)], parts_doclens=[[1, 1, 1, 1]], dim=8)
+    tp, ts = r.topk(s.cuda(), pids.cuda(), k, counts.cuda())
+    for q in range(nq):
+        c = int(counts[q])
+        es, ei = torch.sort(s[q, :c], descending=True, stable=True)
+        kk = min(k, c)
+        assert torch.equal(ts[q, :kk].cpu(), es[:kk]) and torch.equal(tp[q, :kk].cpu(), pids[q, :c][ei[:kk]]), q
+        assert bool((ts[q, kk:].cpu() == float("-inf")).all()) and bool((tp[q, kk:].cpu() == -1).all())
 
 
 # ------------------------------------------------------------------------------------------------------

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--dtype", default="bf16", choices=["fp32", "fp16", "bf16"])
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--no-torch", action="store_true", help="skip the stock-torch comparison (profiling runs)")
     a = ap.parse_args()
     import colbert_amd
     dt = {"fp32": torch.float32, "fp16": torch.float16, "bf16": torch.bfloat16}[a.dtype]
@@ -69,6 +70,8 @@ def main():
     with torch.no_grad():
         res["ours_fwd_only_ms"] = round(timeit(lambda: colbert_amd.score(Q, D, qm, dm), a.iters), 3)
     try:
+        if a.no_torch:
+            raise RuntimeError("skipped (--no-torch)")
         o2, gq2, gd2 = run(torch_score)
         torch.cuda.reset_peak_memory_stats()
         res["torch_ms"] = round(timeit(lambda: run(torch_score), a.iters), 3)

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Condenses rocprofv3 output merged back under gpurun_out/ into small tracked files under profiles/.
 
-    python tools/summarize_profile.py <tag> <trace_dir> [--fetch DIR] [--write DIR] [--sq DIR]
+    python tools/summarize_profile.py <tag> <trace_dir> [--fetch DIR] [--write DIR] [--sq DIR] [--kernels REGEX] [--skip N]
+
+--kernels: which kernels the per-launch PMC / steady-state summary covers (default: k_maxsim); --skip: warm-up launches
+dropped from the steady-state average (default 3).
 
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, kernel names shortened),
 and profiles/<tag>_pmc.json (per-launch PMC values of the maxsim kernels).  HBM traffic follows
@@ -12,6 +15,7 @@ import csv
 import glob
 import json
 import os
+import re
 import sys
 
 
@@ -29,13 +33,15 @@ def main():
     tag, trace = sys.argv[1], sys.argv[2]
     opts = dict(zip(sys.argv[3::2], sys.argv[4::2]))
     os.makedirs("profiles", exist_ok=True)
+    want = re.compile(opts.get("--kernels", "k_maxsim"))
+    skip = int(opts.get("--skip", 3))
     ks = one(os.path.join(trace, "**", "*kernel_stats.csv"))
     if ks:
         rows = list(csv.DictReader(open(ks)))
         with open(f"profiles/{tag}_kernel_stats.csv", "w", newline="") as f:
             w = csv.writer(f)
             w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
-            for r in rows[:12]:
+            for r in rows[:int(opts.get('--rows', 12))]:
                 w.writerow([short(r["Name"])] + [r[k] for k in ("Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev")])
     # steady-state average of the maxsim kernels from the per-dispatch trace (first 3 launches = bench warm-up dropped)
     steady = {}
@@ -43,11 +49,11 @@ def main():
     if kt:
         per = {}
         for r in csv.DictReader(open(kt)):
-            if "k_maxsim" in r["Kernel_Name"]:
+            if want.search(r["Kernel_Name"]):
                 per.setdefault(short(r["Kernel_Name"]).split("(")[0], []).append(
                     (int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
         for k, v in per.items():
-            d = [x[1] for x in sorted(v)][3:]
+            d = [x[1] for x in sorted(v)][skip:]
             if d:
                 steady[k] = {"launches": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
     out = {}
@@ -59,7 +65,7 @@ def main():
         if not cc:
             continue
         for r in csv.DictReader(open(cc)):
-            if "k_maxsim" not in r["Kernel_Name"]:
+            if not want.search(r["Kernel_Name"]):
                 continue
             k = short(r["Kernel_Name"]).split("(")[0]
             e = out.setdefault(k, {}).setdefault(r["Counter_Name"], [])
@@ -82,7 +88,7 @@ def main():
             s["mfma_util(SQ_VALU_MFMA_BUSY_CYCLES/1024 / (GRBM_GUI_ACTIVE/8))"] = (s["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024) / (s["GRBM_GUI_ACTIVE"] / 8)
         summ[k] = s
     for k, v in steady.items():
-        summ.setdefault(k, {})["kernel_trace_steady(after 3 warm-up launches)"] = v
+        summ.setdefault(k, {})[f"kernel_trace_steady(after {skip} warm-up launches)"] = v
     with open(f"profiles/{tag}_pmc.json", "w") as f:
         json.dump(summ, f, indent=1, sort_keys=True)
     print(json.dumps(summ, indent=1, sort_keys=True))
