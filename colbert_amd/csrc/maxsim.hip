@@ -167,10 +167,12 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
   const bool degenerate = nq == 0 || nd == 0 || Lq == 0 || Ld == 0 || h == 0;
   const bool dd_lds = Ld * 256 <= 150 * 1024;  // the doc's [Ld][64] fp32 slab fits in LDS
   // preferred: per-doc inverse index in the caller's workspace (then dD is fully overwritten row by row)
-  const int64_t idx_lds = (2 * ((int64_t)Ld + 1) + (int64_t)nq * Lq) * 4;  // histogram + starts + the doc's item list
+  // per-wave histograms + ranking scratch + bucket starts + the doc's keys parked as 16-bit values
+  const int64_t idx_lds = (int64_t)(2 * BWD_INDEX_WAVES + 1) * ((int64_t)Ld + 1) * 4 +
+                          ((int64_t)nq * Lq <= BWD_INDEX_MAX_PARKED ? (((int64_t)nq * Lq * 2 + 15) & ~15LL) : 0);
   const bool vec8 = (h & 7) == 0;                                            // 16-byte row chunks
   const bool dd_idx = vec8 && workspace && workspace_bytes >= maxsim_score_dense_bwd_workspace(nq, nd, Lq, Ld) &&
-                      idx_lds <= 150 * 1024 && ((int64_t)nd * Ld + 3) / 4 <= 0x7fffffffLL;
+                      idx_lds <= 150 * 1024 && Ld <= 1024 && ((int64_t)nd * Ld + 3) / 4 <= 0x7fffffffLL;
   if (dQ && nQ > 0 && degenerate && hipMemsetAsync(dQ, 0, nQ * sizeof(float), st) != hipSuccess) return MAXSIM_ELAUNCH;
   if (dD && nD > 0 && (degenerate || (!dd_lds && !dd_idx)) && hipMemsetAsync(dD, 0, nD * sizeof(float), st) != hipSuccess)
     return MAXSIM_ELAUNCH;
@@ -195,7 +197,7 @@ int maxsim_score_dense_bwd(const void* Q, const void* D, const void* q_mask, con
       const int lb = (int)idx_lds;                                                                                  \
       rc = allow_lds(k_maxsim_bwd_index, lb);                                                                       \
       if (rc == MAXSIM_OK) {                                                                                        \
-        hipLaunchKernelGGL(k_maxsim_bwd_index, dim3((unsigned)nd), dim3(1024), lb, st, q_mask, d_mask, mask_dtype,  \
+        hipLaunchKernelGGL(k_maxsim_bwd_index, dim3((unsigned)nd), dim3(64 * BWD_INDEX_WAVES), lb, st, q_mask, d_mask, mask_dtype,  \
                            argmax, grad_out, ws_start, ws_items, nq, nd, Lq, Ld);                                   \
         hipLaunchKernelGGL((k_maxsim_bwd_dd_rows<DT>), dim3((unsigned)(((int64_t)nd * Ld + 3) / 4)), dim3(256), 0,  \
                            st, Q, q_mask, d_mask, mask_dtype, grad_out, ws_start, ws_items, dD, nq, nd, Lq, Ld, h); \

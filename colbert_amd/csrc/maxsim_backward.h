@@ -203,21 +203,40 @@ __global__ void __launch_bounds__(1024) k_maxsim_bwd_dd_lds(const void* __restri
 
 // ---- dD through a per-doc inverse index (needs a caller-provided workspace) ------------------------------------
 // Step 1, one workgroup per doc: the (q, m) items that contribute to the doc (coefficient != 0) are counting-sorted by
-// their arg-max token; inside a token's bucket they are then put in ascending item order, so the sums below have a
-// fixed order (bitwise reproducible).  ws_start[d][0..Ld] = bucket offsets, ws_items[d][*] = item ids.
-__global__ void __launch_bounds__(1024) k_maxsim_bwd_index(const void* __restrict__ q_mask,
+// their arg-max token, STABLY -- inside a token's bucket the items stand in ascending item order, so the sums of step 2
+// have a fixed order (bitwise reproducible).  ws_start[d][0..Ld] = bucket offsets, ws_items[d][*] = item ids.
+// The sort is stable by construction and its cost does not depend on how the arg-maxes spread over the tokens: each of
+// the 8 waves owns a contiguous range of items and counts its keys into its own histogram row; a scan over (token, wave)
+// gives every wave its first position in every bucket; the wave then places its items 64 at a time in item order.  A
+// lane's rank among the batch's lanes with the same key comes from rounds of LDS `min`: every unplaced lane offers its
+// lane id to the key's scratch word, the smallest wins the round and takes rank = round number -- as many rounds as the
+// batch's most frequent key has lanes (1-3 when the keys spread, 64 when they all agree), each three LDS operations.
+// (Round 3's form placed items with LDS atomics and insertion-sorted every bucket with one thread: 0.26 ms of the 2.0 ms
+// backward at the reference's step, and quadratic in the longest bucket -- a doc with one live token took ~80 ms.)
+// The keys are computed once (a dependent chain of global loads: arg-max, gradient, two masks) and parked in LDS as
+// 16-bit values for the placement pass.
+// LDS: wcnt[8][Ld + 1] u32, slot[8][Ld + 1] u32, beg[Ld + 1] u32, keys[nitem] u16 (when nitem <= 32768: else recomputed).
+constexpr int BWD_INDEX_WAVES = 8;
+constexpr int BWD_INDEX_MAX_PARKED = 32768;
+__global__ void __launch_bounds__(64 * BWD_INDEX_WAVES) k_maxsim_bwd_index(const void* __restrict__ q_mask,
                                                            const void* __restrict__ d_mask, int mask_dtype,
                                                            const int32_t* __restrict__ argmax,
                                                            const float* __restrict__ grad, int32_t* __restrict__ ws_start,
                                                            int32_t* __restrict__ ws_items, int nq, int nd, int Lq,
                                                            int Ld) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  uint32_t* cnt = (uint32_t*)lds;        // [Ld + 1]: histogram, then running write positions
-  uint32_t* beg = cnt + (Ld + 1);        // [Ld + 1]: bucket starts
-  int32_t* litems = (int32_t*)(beg + (Ld + 1));  // [nitem]: the doc's item list, built and sorted in LDS
-  const int d = blockIdx.x, tid = threadIdx.x, nt = blockDim.x;
+  constexpr int NW = BWD_INDEX_WAVES, NT = 64 * NW;
+  const int L1 = Ld + 1;
+  uint32_t* wcnt = (uint32_t*)lds;       // [NW][L1]: per-wave histogram, then per-wave running write positions
+  uint32_t* slot = wcnt + NW * L1;       // [NW][L1]: per-wave scratch of the ranking rounds (0xFFFFFFFF = free)
+  uint32_t* beg = slot + NW * L1;        // [L1]: bucket starts
+  uint16_t* parked = (uint16_t*)(beg + L1);
+  const int d = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nitem = nq * Lq;
-  for (int i = tid; i <= Ld; i += nt) cnt[i] = 0;
+  const bool park = nitem <= BWD_INDEX_MAX_PARKED;
+  const int per = (nitem + NW - 1) / NW;                       // items per wave (contiguous ranges, in item order)
+  const int it0 = min(nitem, wave * per), it1 = min(nitem, it0 + per);
+  for (int i = tid; i < NW * L1; i += NT) { wcnt[i] = 0; slot[i] = 0xFFFFFFFFu; }
   __syncthreads();
   auto key_of = [&](int it) -> int {  // arg-max token of item `it`, or -1 if it contributes nothing
     const int q = it / Lq, m = it - q * Lq;
@@ -225,38 +244,79 @@ __global__ void __launch_bounds__(1024) k_maxsim_bwd_index(const void* __restric
     float c = grad[(int64_t)q * nd + d];
     if (mask_dtype != MAXSIM_MASK_NONE)
       c *= load_mask(q_mask, mask_dtype, it) * load_mask(d_mask, mask_dtype, (int64_t)d * Ld + n);
-    return c != 0.0f ? n : -1;
+    return (c != 0.0f && n >= 0 && n < Ld) ? n : -1;
   };
-  for (int it = tid; it < nitem; it += nt) {
+  uint32_t* const mycnt = wcnt + wave * L1;
+  uint32_t* const myslot = slot + wave * L1;
+#pragma unroll 4
+  for (int it = it0 + lane; it < it1; it += 64) {
     const int k = key_of(it);
-    if (k >= 0) atomicAdd(&cnt[k], 1u);
+    if (park) parked[it] = (uint16_t)k;                        // (-1 -> 0xFFFF; Ld <= 1024)
+    if (k >= 0) atomicAdd(&mycnt[k], 1u);
   }
   __syncthreads();
-  if (tid == 0) {  // exclusive scan (Ld is a few hundred)
-    uint32_t run = 0;
-    for (int n = 0; n < Ld; ++n) { beg[n] = run; run += cnt[n]; cnt[n] = 0; }
-    beg[Ld] = run;
+  // bucket sizes -> bucket starts (exclusive scan over the tokens, two per thread), then every wave's first position in
+  // every bucket
+  const int t0 = 2 * tid, t1 = 2 * tid + 1;                    // (Ld <= 2 * NT = 1024 for this kernel: checked on the host)
+  uint32_t c0 = 0, c1 = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    c0 += t0 < Ld ? wcnt[w * L1 + t0] : 0u;
+    c1 += t1 < Ld ? wcnt[w * L1 + t1] : 0u;
   }
-  __syncthreads();
-  for (int i = tid; i <= Ld; i += nt) ws_start[(int64_t)d * (Ld + 1) + i] = (int32_t)beg[i];
-  for (int it = tid; it < nitem; it += nt) {
-    const int k = key_of(it);
-    if (k >= 0) litems[beg[k] + atomicAdd(&cnt[k], 1u)] = it;
+  uint32_t incl = c0 + c1;
+#pragma unroll
+  for (int s = 1; s < 64; s <<= 1) {
+    const uint32_t u = __shfl_up(incl, s);
+    if (lane >= s) incl += u;
   }
+  __shared__ uint32_t wave_tot[NW];
+  if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  for (int n = tid; n < Ld; n += nt) {  // fixed order inside each bucket: insertion sort (buckets are short)
-    int32_t* b = litems + beg[n];
-    const int len = (int)(beg[n + 1] - beg[n]);
-    for (int i = 1; i < len; ++i) {
-      const int32_t v = b[i];
-      int j = i - 1;
-      while (j >= 0 && b[j] > v) { b[j + 1] = b[j]; --j; }
-      b[j + 1] = v;
+  uint32_t base = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    const uint32_t u = wave_tot[w];
+    base += w < wave ? u : 0u;
+    total += u;
+  }
+  uint32_t run0 = base + incl - c0 - c1, run1 = run0 + c0;     // starts of buckets t0, t1
+  if (t0 < Ld) beg[t0] = run0;
+  if (t1 < Ld) beg[t1] = run1;
+#pragma unroll
+  for (int w = 0; w < NW; ++w) {
+    if (t0 < Ld) { const uint32_t c = wcnt[w * L1 + t0]; wcnt[w * L1 + t0] = run0; run0 += c; }
+    if (t1 < Ld) { const uint32_t c = wcnt[w * L1 + t1]; wcnt[w * L1 + t1] = run1; run1 += c; }
+  }
+  if (tid == 0) beg[Ld] = total;
+  __syncthreads();
+  for (int i = tid; i <= Ld; i += NT) ws_start[(int64_t)d * L1 + i] = (int32_t)beg[i];
+  // placement, in item order, batch by batch: position = the wave's running position in the bucket + the lane's rank among
+  // the batch's lanes with the same key.  (Only this wave touches its rows; LDS operations of a wave execute in order.)
+  int32_t* const out = ws_items + (int64_t)d * nitem;
+  for (int b0 = it0; b0 < it1; b0 += 64) {
+    const int it = b0 + lane;
+    int k = -1;
+    if (it < it1) {
+      if (park) { const uint16_t v = parked[it]; k = v == 0xFFFFu ? -1 : (int)v; }
+      else k = key_of(it);
+    }
+    const uint32_t p0 = k >= 0 ? mycnt[k] : 0u;
+    bool open = k >= 0;
+    int rank = 0;
+    for (int round = 0; __any(open); ++round) {
+      if (open) atomicMin(&myslot[k], (uint32_t)lane);
+      if (open && myslot[k] == (uint32_t)lane) {
+        rank = round;
+        open = false;
+        myslot[k] = 0xFFFFFFFFu;
+      }
+    }
+    if (k >= 0) {
+      out[p0 + rank] = it;
+      atomicAdd(&mycnt[k], 1u);
     }
   }
-  __syncthreads();
-  const int total = (int)beg[Ld];
-  for (int i = tid; i < total; i += nt) ws_items[(int64_t)d * nitem + i] = litems[i];
 }
 
 // Step 2, one wave per doc token (row of dD): dD[d, n, :] = d_mask * sum over the row's items of g * q_mask * Q[item, :].

@@ -66,16 +66,19 @@ def test_row_block_table(ca):
 
 
 @pytest.mark.parametrize("ndocs,lo,hi,n,distinct", [
-    (20000, 1, 3, 16384, None),        # ~11000 distinct docs: the hash set overflows -> full-sort path
-    (20000, 1, 3, 16384, 6000),        # below the set's capacity
-    (20000, 1, 3, 16384, 6145),
-    (20000, 1, 3, 16384, 7000),        # 8192-slot table at load factor 0.85: long probe chains, either path
-    (20000, 1, 3, 16384, 8192),        # exactly as many distinct docs as slots
-    (20000, 1, 3, 16384, 8193),
+    (20000, 1, 3, 16384, None),        # ~11000 distinct docs in the 16384-slot set (load factor 0.68)
+    (200000, 1, 3, 16384, None),       # ~15700 distinct docs: probe chains pass 64 -> the full-sort path
+    (20000, 1, 3, 16384, 6000),
+    (20000, 1, 3, 16384, 8192),        # sorted as exactly 8192 keys
+    (20000, 1, 3, 16384, 8193),        # ... and as 16384
+    (20000, 1, 3, 16384, 13000),       # load factor 0.79: long probe chains, either path
+    (20000, 1, 3, 16384, 15000),
+    (20000, 1, 3, 16384, 16384),       # every id another doc: as many distinct docs as slots
     (20000, 1, 3, 9000, None),
     (3000, 0, 400, 16384, None),       # long docs (several 64-row blocks each) and empty docs
-    (3000, 0, 400, 4096, None),        # n <= 4096: smaller buffers
-    (3000, 0, 400, 2048, None),        # 4096-slot table
+    (3000, 0, 400, 4096, None),        # n <= 4096: 8192-slot set
+    (3000, 0, 400, 2048, None),        # 4096-slot set
+    (3000, 0, 400, 2048, 2048),        # ... full to load factor 0.5
     (3000, 0, 400, 700, None),
     (5, 1, 2, 16384, None),            # a handful of docs
 ])
@@ -95,7 +98,8 @@ def test_ids_to_pids_hash_and_overflow_paths(ca, ndocs, lo, hi, n, distinct):
         offs = torch.tensor([0] + doclens).cumsum(0)
         e = torch.empty(nq, n, dtype=torch.int64)
         for q in range(nq):
-            docs = torch.randperm(ndocs, generator=g)[:distinct - (q & 1)]            # odd rows: one doc fewer
+            live = torch.tensor([i for i, dl in enumerate(doclens) if dl > 0])
+            docs = live[torch.randperm(live.numel(), generator=g)[:distinct - (q & 1)]]    # odd rows: one doc fewer
             pick = torch.cat([docs, docs[torch.randint(0, docs.numel(), (n - docs.numel(),), generator=g)]])
             e[q] = offs[pick][torch.randperm(n, generator=g)]
     e[1, ::97] = -1                                                                    # FAISS "no neighbour"
@@ -188,3 +192,42 @@ def test_retrieve_batch_leaves_the_callers_ids_alone(ca):
         n = min(50, int(cnt_a[q]))
         assert p == tp[q, :n].tolist() and s == ts[q, :n].tolist()
     assert len(exp) == nq
+
+
+@pytest.mark.parametrize("dtype,atol,nq", [(torch.float32, 2e-4, 40), (torch.bfloat16, 3e-2, 40),
+                                           (torch.float32, 2e-3, 530)])     # 16960 items per doc: batches beyond the register-held ones
+def test_backward_with_skewed_argmax_buckets(ca, dtype, atol, nq):
+    """The dD pass counting-sorts a doc's (q, m) items by arg-max token (maxsim_backward.h, k_maxsim_bwd_index).  Docs whose
+    arg-maxes all fall on ONE token (a doc with a single live token; a doc with one dominant token), empty buckets, masked
+    query tokens and a doc with no contribution at all, against torch autograd through the four ops of BaseModel.py:41-45;
+    and bitwise reproducible from run to run (the sort is stable: fixed summation order)."""
+    g = torch.Generator().manual_seed(41)
+    nd, lq, ld, h = 9, 32, 96, 64
+    Q = F.normalize(torch.randn(nq, lq, h, generator=g), dim=-1)
+    D = F.normalize(torch.randn(nd, ld, h, generator=g), dim=-1) * 0.3
+    D[1, 5] = F.normalize(Q.mean((0, 1)), dim=-1) * 3.0          # doc 1: token 5 wins nearly every (q, m)
+    qm = (torch.rand(nq, lq, generator=g) > 0.2).long()
+    dm = torch.ones(nd, ld, dtype=torch.long)
+    dm[0, 1:] = 0                                                # doc 0: one live token -> one bucket of nq * Lq items
+    dm[2, 50:] = 0
+    w = torch.randn(nq, nd, generator=g)
+    w[:, 3] = 0.0                                                # doc 3 receives no gradient: every item dropped
+
+    def run(fn, Q0, D0):
+        q = Q0.clone().cuda().requires_grad_(True)
+        dd = D0.clone().cuda().requires_grad_(True)
+        out = fn(q, dd, qm.cuda(), dm.cuda())
+        (out.float() * w.cuda()).sum().backward()
+        return out.detach().float().cpu(), q.grad.float().cpu(), dd.grad.float().cpu()
+
+    def torch_score(q, dd, qmask, dmask):
+        return torch.einsum("qmh,dnh->qdmn", q * qmask[..., None], dd * dmask[..., None]).max(-1).values.sum(-1)
+
+    Qt, Dt = Q.to(dtype), D.to(dtype)
+    o1, gq1, gd1 = run(ca.score, Qt, Dt)
+    o2, gq2, gd2 = run(torch_score, Qt.float(), Dt.float())
+    assert (o1 - o2).abs().max() <= atol * 10
+    assert (gq1 - gq2).abs().max() <= atol and (gd1 - gd2).abs().max() <= atol * 4
+    assert float(gd1[3].abs().max()) == 0.0 and float(gd1[0, 1:].abs().max()) == 0.0
+    o3, gq3, gd3 = run(ca.score, Qt, Dt)
+    assert torch.equal(gd1, gd3) and torch.equal(gq1, gq3)
