@@ -228,6 +228,7 @@ int64_t maxsim_worklist_bytes(int nq, int ncand) {
   return (worklist_items_word(nq) + 2 * ((int64_t)nq * ncand + 1)) * (int64_t)sizeof(int32_t);
 }
 
+constexpr int LIST_FUSED_FILL_NQ = 8;  // up to this many rows the scan kernel also fills (one launch instead of two)
 constexpr int LIST_MIN_ITEMS = 1792;  // 448 workgroups of 4 waves: pick_docs_per_wave's rule, applied on the device
 
 static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, const int32_t* q_len,
@@ -280,8 +281,13 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
                            (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16);
     const int slots_knob = MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1);  // (diagnostic builds: 0 switches the one-round rule off)
     const int list_slots = slots_knob >= 0 ? slots_knob : (uni_short ? 4096 : 2048);
-    hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, list_slots, wl);
-    hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
+    if (nq <= LIST_FUSED_FILL_NQ) {  // a handful of rows: scan + fill in one launch
+      hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, list_slots, wl, scores);
+    } else {
+      hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64, LIST_MIN_ITEMS, list_slots, wl,
+                         (float*)nullptr);
+      hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(256), 0, st, cand_count, nq, ncand, wl, scores, 1);
+    }
     if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
     // k_worklist_scan may settle on any docs-per-item in [D0 / 2, 2 D0] (and keeps halving while the launch is below its
     // minimum): the grid is sized for the SMALLEST it can pick, so that no workgroup runs two items while CU slots idle
@@ -308,9 +314,14 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
       p.worklist = worklist;
       const int D0 = stream_list_docs_per_item(p) * lw;
       int32_t* const wl = (int32_t*)worklist;
-      hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64 * lw, 256,
-                         MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) >= 0 ? MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) : 256, wl);  // (one workgroup per CU is resident)
-      hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(64), 0, st, cand_count, nq, ncand, wl, scores, 1);
+      const int slots768 = MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) >= 0 ? MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1) : 256;  // (one workgroup per CU is resident)
+      if (nq <= LIST_FUSED_FILL_NQ) {
+        hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64 * lw, 256, slots768, wl, scores);
+      } else {
+        hipLaunchKernelGGL(k_worklist_scan, dim3(1), dim3(1024), 0, st, cand_count, nq, ncand, D0, 64 * lw, 256, slots768, wl,
+                           (float*)nullptr);
+        hipLaunchKernelGGL(k_worklist_fill, dim3((unsigned)nq), dim3(256), 0, st, cand_count, nq, ncand, wl, scores, 1);
+      }
       if (check_launch() != MAXSIM_OK) return MAXSIM_ELAUNCH;
       const int Dlow = D0 / 2 > 1 ? D0 / 2 : 1;   // (the smallest docs-per-item the scan can settle on, as above)
       const int64_t by_rows = (int64_t)nq * ((ncand + Dlow - 1) / Dlow), small = 2 * 256 + nq;
@@ -391,10 +402,12 @@ int maxsim_shard_candidates(const int64_t* cand_global, int nq, int ncand, int64
 static int topk_count(const float* scores, const int64_t* pids, int nq, int ncand, int k, float* out_scores,
                       int64_t* out_pids, int32_t* counter, uint32_t* done_flag, uint32_t ticket, hipStream_t st,
                       const int32_t* counts = nullptr) {
-  const int groups = (ncand + TOPK_CAND_PER_WG - 1) / TOPK_CAND_PER_WG;
+  int groups = (ncand + TOPK_CAND_PER_WG - 1) / TOPK_CAND_PER_WG;
+  // counted rows of a big batch: at most 8 workgroups per row, each looping over its candidate groups (see k_topk_count)
+  if (counts && !done_flag && nq >= 64 && groups > 8) groups = 8;
   if ((int64_t)nq * groups > 0x7fffffffLL) return MAXSIM_ERANGE;
   hipLaunchKernelGGL(k_topk_count, dim3((unsigned)(nq * groups)), dim3(256), 0, st, scores, pids, ncand, k, out_scores,
-                     out_pids, groups, counter, done_flag, ticket, counts);
+                     out_pids, groups, counter, done_flag, ticket, counts, groups);
   return check_launch();
 }
 

@@ -68,9 +68,13 @@ __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ sc
                                                     int ncand, int k, float* __restrict__ out_s,
                                                     int64_t* __restrict__ out_p, int groups, int32_t* counter,
                                                     uint32_t* done_flag, uint32_t ticket,
-                                                    const int32_t* __restrict__ counts) {
+                                                    const int32_t* __restrict__ counts, int gstride) {
   __shared__ uint64_t keys[2048];
   const int tid = threadIdx.x;
+  // `groups` workgroups per query; workgroup g ranks the candidate groups g, g + gstride, ... (gstride == groups: one each.
+  // Counted rows of a big batch take fewer workgroups per row than the row is wide: most of a 1000-wide row of a doc
+  // shard's share is padding, and 63 workgroups per row that load the keys to find they have nothing to rank cost more
+  // than 8 that loop -- 2048 rows x 125 live: 61 -> ~25 us)
   const int q = blockIdx.x / groups, g = blockIdx.x - q * groups;
   const int row_w = ncand;  // row pitch of scores / pids
   // counted rows: only the first counts[q] slots of the row are candidates (the rest is (-inf, -1) padding, which is also
@@ -89,7 +93,8 @@ __global__ void __launch_bounds__(256) k_topk_count(const float* __restrict__ sc
   if (done_flag)  // the host may read the outputs while the kernel is still running: system-scope write-through
     topk_rank_group<true>(keys, ncand, n16, g, k, pid_row, out_s + (int64_t)q * k, out_p + (int64_t)q * k);
   else
-    topk_rank_group<false>(keys, ncand, n16, g, k, pid_row, out_s + (int64_t)q * k, out_p + (int64_t)q * k);
+    for (int gg = g; gg == g || gg * TOPK_CAND_PER_WG < ncand; gg += gstride)
+      topk_rank_group<false>(keys, ncand, n16, gg, k, pid_row, out_s + (int64_t)q * k, out_p + (int64_t)q * k);
   // slots k' in [ncand, k) (k > ncand): (-inf, -1), written by the query's first workgroup
   if (g == 0)
     for (int i = ncand + tid; i < k; i += 256) {

@@ -30,13 +30,20 @@ __device__ __forceinline__ int wl_row_count(const int32_t* __restrict__ counts, 
   return min(max(counts[q], 0), ncand);
 }
 
+__device__ __forceinline__ void worklist_fill_row(const int32_t* __restrict__ counts, int q, int nq, int ncand,
+                                                  int32_t* __restrict__ wl, float* __restrict__ scores, int fill_tail,
+                                                  int D, int base, int tid, int nt);
+
 // One workgroup: (1) the number of live candidates -> docs per wave item D (the host's target D0 = a ~1.4 k-token stream,
 // halved while the launch would have fewer than `min_items` items: a small launch is better off with more, shorter
 // streams -- the rule pick_docs_per_wave applies on the host to static grids; then, for lists of 2-4 rounds of the
 // kernel's `slots` resident wave (workgroup) slots, the cut that wastes the least of the last round --
 // refine_docs_per_wave's reasoning, on the device); (2) exclusive scan of ceil(count / D).
+// fused_scores != nullptr (a handful of queries: the online driver serving one query at a time): this workgroup also does
+// k_worklist_fill's work -- one launch and one dependent launch gap less on a ~100 us call.
 static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __restrict__ counts, int nq, int ncand, int D0,
-                                                        int Dmax, int min_items, int slots, int32_t* __restrict__ wl) {
+                                                        int Dmax, int min_items, int slots, int32_t* __restrict__ wl,
+                                                        float* __restrict__ fused_scores = nullptr) {
   __shared__ long long red[16];
   __shared__ int wsum[16];
   __shared__ int carry_s, D_s;
@@ -99,25 +106,42 @@ static __global__ void __launch_bounds__(1024) k_worklist_scan(const int32_t* __
     item_start[nq] = carry_s;
     wl[0] = carry_s;
   }
+  if (fused_scores != nullptr) {
+    __syncthreads();                     // (item_start was written by this workgroup: visible after the barrier)
+    for (int q = 0; q < nq; ++q) worklist_fill_row(counts, q, nq, ncand, wl, fused_scores, 1, D, item_start[q], tid, 1024);
+  }
 }
 
-// One wave per query: the row's items (its docs dealt evenly: item j of w takes slots [j c / w, (j + 1) c / w)) and the
-// -inf tail of the row's scores (slots past the live count are padding slots: what the static kernels write there).
-static __global__ void __launch_bounds__(64) k_worklist_fill(const int32_t* __restrict__ counts, int nq, int ncand,
-                                                      int32_t* __restrict__ wl, float* __restrict__ scores,
-                                                      int fill_tail) {
-  const int q = blockIdx.x, lane = threadIdx.x;
+// A row's items (its docs dealt evenly: item j of w takes slots [j c / w, (j + 1) c / w)) and the -inf tail of the row's
+// scores (slots past the live count are padding slots: what the static kernels write there), by `nt` threads.
+__device__ __forceinline__ void worklist_fill_row(const int32_t* __restrict__ counts, int q, int nq, int ncand,
+                                                  int32_t* __restrict__ wl, float* __restrict__ scores, int fill_tail,
+                                                  int D, int base, int tid, int nt) {
   const int c = wl_row_count(counts, q, ncand);
-  const int D = wl[1];
   const int w = (c + D - 1) / D;
-  const int base = wl[WL_HEADER_WORDS + q];
   int2* const items = (int2*)(wl + worklist_items_word(nq));
-  for (int j = lane; j < w; j += 64) {
+  for (int j = tid; j < w; j += nt) {
     const int b = (int)((long long)j * c / w), e = (int)((long long)(j + 1) * c / w);
     items[base + j] = make_int2(q, b | ((e - b) << WL_SLOT_BITS));
   }
-  if (fill_tail)
-    for (int i = c + lane; i < ncand; i += 64) scores[(int64_t)q * ncand + i] = NEG_INF;
+  if (fill_tail) {
+    float* const row = scores + (int64_t)q * ncand;
+    // 16-byte stores over the aligned middle of the tail, single floats at its two ends
+    const int a0 = min(ncand, c + (int)((4 - (((uintptr_t)(row + c) >> 2) & 3)) & 3));
+    const int a1 = a0 + ((ncand - a0) & ~3);
+    for (int i = c + tid; i < a0; i += nt) row[i] = NEG_INF;
+    const float4 ninf = make_float4(NEG_INF, NEG_INF, NEG_INF, NEG_INF);
+    for (int i = a0 + 4 * tid; i < a1; i += 4 * nt) *(float4*)(row + i) = ninf;
+    for (int i = a1 + tid; i < ncand; i += nt) row[i] = NEG_INF;
+  }
+}
+
+// One workgroup of 256 threads per query.
+static __global__ void __launch_bounds__(256) k_worklist_fill(const int32_t* __restrict__ counts, int nq, int ncand,
+                                                      int32_t* __restrict__ wl, float* __restrict__ scores,
+                                                      int fill_tail) {
+  const int q = blockIdx.x;
+  worklist_fill_row(counts, q, nq, ncand, wl, scores, fill_tail, wl[1], wl[WL_HEADER_WORDS + q], threadIdx.x, 256);
 }
 
 }  // namespace maxsim
