@@ -93,8 +93,15 @@ class ColbertRanker:
     index_dtype           : storage dtype in HBM (reference: fp16, colbert_ranker.py:62)
     fp32_mode             : for an fp32 index with dim 128: "exact" (default; f32-input MFMA, an exact fp32 fmaf chain),
                             "bf16x3" (both operands cut exactly into three bf16 pieces, six piece products on the bf16
-                            matrix pipe: fp32-class accuracy, no magnitude limit, ~7 % faster) or "fast" (fp16 hi+lo
-                            pieces, three products, |error| ~1e-6 on a score, needs |x| < 65504, ~11 % faster)
+                            matrix pipe: fp32-class accuracy, no magnitude limit, ~7 % faster on uniform 180-token docs,
+                            ~15 % on ragged docs) or "fast" (fp16 hi+lo pieces, three products, |error| ~1e-6 on a
+                            score, needs |x| < 65504, ~11 % faster).
+                            When to pick what: keep "exact" when scores must be bitwise reproducible against an fp32
+                            fmaf chain (the parity tests' strictest form); pick "bf16x3" for an fp32 index -- L2-normalised
+                            rows or not -- when the stated tolerance (|d| <= 1e-4 on a score) is the requirement and
+                            throughput matters: the exact mode is power-capped at 0.73 (uniform) / 0.67-0.70 (ragged) of
+                            the HBM peak, bf16x3 runs at 0.78 / 0.80.  The reference stores fp16 (colbert_ranker.py:62):
+                            with index_dtype=torch.float16 (the default here) the mode does not apply.
     strides               : length-bucket strides to use instead of the percentiles of THIS index's doclens
                             (colbert_ranker.py:36-40).  A doc-shard must be given the strides of the whole index
                             (``sharded.global_strides``): the 0-floor depends on them (:90, :108-109)
