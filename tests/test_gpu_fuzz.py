@@ -402,3 +402,61 @@ def test_random_retrieve_batch(ca, c):
         np.testing.assert_allclose(np.array(gs), np.array(es), rtol=0, atol=atol)
         all_s = dict(zip(pids, ref.all_scores(q_live.unsqueeze(0).permute(0, 2, 1), pids).tolist()))
         assert len(set(gp)) == len(gp) and all(abs(all_s[p] - s) <= atol for p, s in zip(gp, gs))
+
+
+# ------------------------------------------------------------------------------------------------------
+# the doc-sharded batched driver (round 4): GLOBAL token rows -> every shard's rows -> distinct pids -> counted rerank ->
+# counted local top-k -> merge, against the unsharded driver on the same ids
+# ------------------------------------------------------------------------------------------------------
+def _shard_retrieve_cases():
+    rng = np.random.RandomState(4242 + SEED)
+    return [dict(i=i, world=int(rng.choice([2, 3, 5, 8])), bs=int(rng.choice([1, 3, 11])), lq=int(rng.choice([4, 16, 32])),
+                 depth=int(rng.choice([1, 8, 64, 512])), topk=int(rng.choice([1, 10, 100])), dtype=str(rng.choice(["fp32", "fp16"])),
+                 docs=str(rng.choice(["ragged", "short", "uniform8"])), pad=bool(rng.rand() < 0.4), skew=bool(rng.rand() < 0.3))
+            for i in range(max(6, int(os.environ.get("MAXSIM_FUZZ_CASES", "48")) // 4))]
+
+
+@pytest.mark.parametrize("c", _shard_retrieve_cases(), ids=lambda c: f"{c['i']}-w{c['world']}-bs{c['bs']}-Lq{c['lq']}-fd{c['depth']}-k{c['topk']}-{c['dtype']}-{c['docs']}{'-pad' if c['pad'] else ''}{'-skew' if c['skew'] else ''}")
+def test_random_sharded_retrieve(ca, c):
+    """ShardedRanker.local_retrieve_topk on 2-8 pid-range shards (one after another on this GPU), merged, equals
+    colbert_amd.retrieve_batch on the whole index: same score lists bit for bit, same pids up to ties, short rows padded
+    with (-1, -inf).  The ANN result is a stand-in: random GLOBAL token rows, some -1, optionally all inside one shard."""
+    from colbert_amd.ranker import reference_strides
+    from colbert_amd.retriever import prepare_embedding_ids
+    from colbert_amd.sharded import ShardedRanker, merge_gathered, shard_range
+    gen = torch.Generator().manual_seed(8000 + c["i"] + 100003 * SEED)
+    world, bs, lq, depth, topk = c["world"], c["bs"], c["lq"], c["depth"], c["topk"]
+    tdt = torch.float32 if c["dtype"] == "fp32" else torch.float16
+    ndocs, h = 700, 128
+    doclens = [max(d, 1) for d in _doclens(c["docs"], ndocs, gen)]
+    emb = F.normalize(torch.randn(sum(doclens), h, generator=gen), dim=-1).to(tdt)
+    whole = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=tdt)
+    offs = np.concatenate([[0], np.cumsum(doclens)])
+    ntok = int(offs[-1])
+    Q = F.normalize(torch.randn(bs, lq, h, generator=gen), dim=-1).cuda()
+    keep = (torch.rand(bs, lq, generator=gen) < 0.75).long()
+    keep[:, 0] = 1
+    hi_row = int(offs[shard_range(ndocs, 0, world)[1]]) if c["skew"] else ntok      # skew: every neighbour lives on shard 0
+    ids = torch.randint(0, hi_row, (bs, lq, depth), generator=gen)
+    if c["pad"]:
+        ids[torch.rand(bs, lq, depth, generator=gen) < 0.2] = -1
+    ids, keep = ids.cuda(), keep.cuda()
+    exp = ca.retrieve_batch(whole, Q, keep, topk=topk, embedding_ids=ids)
+    k = min(topk, lq * depth)
+    gstr = reference_strides(torch.tensor(doclens))
+    keep_b, ids_b = prepare_embedding_ids(Q.device, Q, keep, ids, mask_ids=False)
+    tops = []
+    for rank in range(world):
+        lo, hi = shard_range(ndocs, rank, world)
+        r = ca.ColbertRanker(parts=[emb[offs[lo]:offs[hi]]], parts_doclens=[doclens[lo:hi]], dim=h, index_dtype=tdt, strides=gstr)
+        sh = ShardedRanker(r, lo, hi, sync_strides=False, n_docs_total=ndocs, tok_lo=int(offs[lo]))
+        tops.append(sh.local_retrieve_topk(Q, keep_b, ids_b.reshape(bs, -1), k))
+    gs, gp = torch.stack([t[1] for t in tops]), torch.stack([t[0] for t in tops])
+    mp, ms = merge_gathered(gs, gp, k, whole.topk)
+    for qi, (ep, es) in enumerate(exp):
+        n = len(ep)
+        assert ms[qi, :n].tolist() == es, (qi, n)
+        assert sorted(mp[qi, :n].tolist()) == sorted(ep)
+        by = dict(zip(ep, es))
+        assert all(by[p] == s for p, s in zip(mp[qi, :n].tolist(), ms[qi, :n].tolist()))
+        assert bool((mp[qi, n:] == -1).all()) and bool(torch.isinf(ms[qi, n:]).all())
