@@ -546,7 +546,7 @@ int maxsim_hbm_read_probe(const void* buf, int64_t bytes, int variant, int64_t* 
 
 int64_t maxsim_row_blocks_bytes(int64_t n_tokens) {
   if (n_tokens < 0) return MAXSIM_EINVAL;
-  return (((n_tokens + (1 << kRowBlockShift) - 1) >> kRowBlockShift) + 1) * 4;
+  return (((n_tokens + (1 << kRowBlockShift) - 1) >> kRowBlockShift) + 1) * 8;
 }
 
 int maxsim_build_row_blocks(const int64_t* tok_offsets, int64_t n_docs, int64_t n_tokens, void* row_blocks, void* stream) {
@@ -555,8 +555,9 @@ int maxsim_build_row_blocks(const int64_t* tok_offsets, int64_t n_docs, int64_t 
   const int64_t nblocks = (n_tokens + (1 << kRowBlockShift) - 1) >> kRowBlockShift;
   const int64_t wgs = (nblocks + 1 + 255) / 256;
   if (wgs > 0x7fffffffLL) return MAXSIM_ERANGE;
-  hipLaunchKernelGGL(k_build_row_blocks, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, tok_offsets, n_docs, nblocks,
-                     (uint32_t*)row_blocks);
+  if (((uintptr_t)row_blocks & 7) != 0) return MAXSIM_EINVAL;
+  hipLaunchKernelGGL(k_build_row_blocks, dim3((unsigned)wgs), dim3(256), 0, (hipStream_t)stream, tok_offsets, n_docs, n_tokens,
+                     nblocks, (uint64_t*)row_blocks);
   return check_launch();
 }
 
@@ -568,7 +569,7 @@ int maxsim_embedding_ids_to_pids_ex(const int64_t* emb_ids, int nq, int n, int i
   if (n > 16384 || n_docs > 0xfffffffeLL) return MAXSIM_ERANGE;
   if (tok_keep && (ids_per_token <= 0 || n % ids_per_token != 0)) return MAXSIM_EINVAL;
   if (nq == 0) return MAXSIM_OK;
-  if (!emb_ids || !out_pids || !out_count || (n_docs > 0 && !tok_offsets)) return MAXSIM_EINVAL;
+  if (!emb_ids || !out_pids || !out_count || (n_docs > 0 && !tok_offsets) || ((uintptr_t)row_blocks & 7) != 0) return MAXSIM_EINVAL;
   int P = 2048;
   while (P < n) P <<= 1;
   int log_ts = 12;                                         // hash set: min(16384, 2 P) slots
@@ -579,7 +580,7 @@ int maxsim_embedding_ids_to_pids_ex(const int64_t* emb_ids, int nq, int n, int i
   int rc = allow_lds(k_unique_pids, ldsb);
   if (rc) return rc;
   hipLaunchKernelGGL(k_unique_pids, dim3((unsigned)nq), dim3(1024), ldsb, (hipStream_t)stream, emb_ids, n, P, log_ts, id_base,
-                     tok_keep, ipt_arg, tok_offsets, n_docs, n_tokens, (const uint32_t*)row_blocks, out_pids,
+                     tok_keep, ipt_arg, tok_offsets, n_docs, n_tokens, (const uint64_t*)row_blocks, out_pids,
                      out_count);
   return check_launch();
 }

@@ -13,21 +13,40 @@ namespace maxsim {
 constexpr int kRowBlockShift = 6;  // one row-block table entry per 64 token rows
 constexpr uint32_t kNoKey = 0xFFFFFFFFu;
 
-// row_blocks[b] = the doc that holds token row b * 64 (the LAST doc whose first row is <= it: empty docs that start at the
-// same row come before the one that owns it), b = 0 .. nblocks - 1; row_blocks[nblocks] = n_docs - 1.
+// row_blocks[b], b = 0 .. nblocks - 1, describes the 64 token rows from b * 64 on (8 bytes per entry):
+//   bits  0..31  the doc that holds row b * 64 (the LAST doc whose first row is <= it: empty docs that start at the same
+//                row come before the one that owns it)
+//   bits 32..38  0 = the whole block belongs to that doc; else the offset (1..63) inside the block at which the NEXT doc
+//                (doc + 1) starts -- the common case for docs of 64 tokens and more
+//   bit  39      the block holds more than two docs, or its second doc is not doc + 1 (empty docs in between): look the row
+//                up in tok_offsets between this entry's doc and the next entry's
+// row_blocks[nblocks] = {n_docs - 1}: the upper end of the last block's search.  One 8-byte load answers a lookup in the
+// common case (the 4-byte form of round 4's first version took two table loads + a prefix-sum load per id: 33 of the 67 us
+// of a 256-query launch went into those divergent loads).
 __global__ void __launch_bounds__(256) k_build_row_blocks(const int64_t* __restrict__ tok_offsets, int64_t n_docs,
-                                                          int64_t nblocks, uint32_t* __restrict__ row_blocks) {
+                                                          int64_t n_tokens, int64_t nblocks,
+                                                          uint64_t* __restrict__ row_blocks) {
   const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (b > nblocks) return;
-  const int64_t e = b << kRowBlockShift;
-  int64_t lo = 0, hi = n_docs;  // invariant: tok_offsets[i] <= e for i < lo ; > e for i >= hi
-  if (b == nblocks) lo = n_docs;
-  else
+  auto doc_of = [&](int64_t e) {  // number of docs whose first row is <= e, minus one
+    int64_t lo = 0, hi = n_docs;  // invariant: tok_offsets[i] <= e for i < lo ; > e for i >= hi
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
       if (tok_offsets[mid] <= e) lo = mid + 1; else hi = mid;
     }
-  row_blocks[b] = (uint32_t)(lo > 0 ? lo - 1 : 0);
+    return lo > 0 ? lo - 1 : 0;
+  };
+  if (b == nblocks) {
+    row_blocks[b] = (uint64_t)(uint32_t)(n_docs > 0 ? n_docs - 1 : 0);
+    return;
+  }
+  const int64_t r0 = b << kRowBlockShift;
+  const int64_t r1 = (r0 + (1 << kRowBlockShift) < n_tokens ? r0 + (1 << kRowBlockShift) : n_tokens) - 1;  // last row of the block
+  const int64_t d0 = doc_of(r0), d1 = doc_of(r1);
+  uint64_t ent = (uint64_t)(uint32_t)d0;
+  if (d1 == d0 + 1) ent |= (uint64_t)(tok_offsets[d1] - r0) << 32;   // (1..63: d1's first row lies inside the block, past r0)
+  else if (d1 != d0) ent |= 1ull << 39;
+  row_blocks[b] = ent;
 }
 
 // The token row (relative to id_base) behind slot i of query q, or -1: FAISS pads missing neighbours with -1, rows of
@@ -151,7 +170,7 @@ __device__ __forceinline__ void unique_by_full_sort(uint32_t* keys, uint32_t* sc
 __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict__ emb_ids, int n, int P, int log_ts,
                                                       int64_t id_base, const uint8_t* __restrict__ tok_keep, int ids_per_token,
                                                       const int64_t* __restrict__ tok_offsets, int64_t n_docs,
-                                                      int64_t n_tokens, const uint32_t* __restrict__ row_blocks,
+                                                      int64_t n_tokens, const uint64_t* __restrict__ row_blocks,
                                                       int64_t* __restrict__ out_pids, int32_t* __restrict__ out_count) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   constexpr int nt = 1024;
@@ -178,8 +197,12 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
       lo[g] = 0;
       hi[g] = e[g] >= 0 ? (uint32_t)last : 0u;
       if (row_blocks != nullptr && e[g] >= 0) {
-        lo[g] = row_blocks[e[g] >> kRowBlockShift];
-        hi[g] = row_blocks[(e[g] >> kRowBlockShift) + 1];
+        const int64_t b = e[g] >> kRowBlockShift;
+        const uint64_t ent = row_blocks[b];
+        const uint32_t d0 = (uint32_t)ent, bnd = (uint32_t)(ent >> 32) & 127u;
+        lo[g] = d0;
+        if ((ent >> 39) & 1) hi[g] = (uint32_t)row_blocks[b + 1];                     // rare: search between the two entries
+        else lo[g] = hi[g] = d0 + ((bnd != 0 && ((uint32_t)e[g] & 63u) >= bnd) ? 1u : 0u);
       }
     }
     // the doc of row e: the LAST pid in [lo, hi] whose first row is <= e (tok_offsets[lo] <= e holds on entry)

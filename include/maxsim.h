@@ -188,9 +188,10 @@ int maxsim_embedding_ids_to_pids(const int64_t* emb_ids, int nq, int n, const in
  *               dense_server_client.py:45).  n must be a multiple of ids_per_token when tok_keep is given.
  *   id_base   : subtracted from every id first; ids outside [id_base, id_base + n_tokens) are dropped.  A doc shard passes
  *               the global token row of its first token and gets LOCAL pids of the rows that are its own.
- *   row_blocks: NULL, or the table maxsim_build_row_blocks wrote for this (tok_offsets, n_docs, n_tokens): the doc of
- *               every 64th token row, 4 bytes each (the reference keeps 4 bytes for EVERY row: emb2pid,
- *               colbert_ranker.py:163-174).  With it a lookup is ~3 loads instead of a ~log2(n_docs)-step binary search.
+ *   row_blocks: NULL, or the table maxsim_build_row_blocks wrote for this (tok_offsets, n_docs, n_tokens), 8-byte aligned:
+ *               8 bytes per 64 token rows -- the doc of the block's first row and where the next doc starts inside it (the
+ *               reference keeps 4 bytes for EVERY row: emb2pid, colbert_ranker.py:163-174).  With it a lookup is one 8-byte
+ *               load in the common case instead of a ~log2(n_docs)-step binary search.
  * Same output contract as maxsim_embedding_ids_to_pids.
  */
 int maxsim_embedding_ids_to_pids_ex(const int64_t* emb_ids, int nq, int n, int ids_per_token, const uint8_t* tok_keep,

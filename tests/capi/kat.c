@@ -217,7 +217,7 @@ int main(void) {
     int32_t n6 = -1;
     hipDeviceSynchronize();
     hipMemcpy(out6, dout6, 48, hipMemcpyDeviceToHost); hipMemcpy(&n6, dn6, 4, hipMemcpyDeviceToHost);
-    CHECK(rc == MAXSIM_OK && rc2 == MAXSIM_OK && rbb == 8 && n6 == 2 && out6[0] == 0 && out6[1] == 2 && out6[2] == -1 && out6[5] == -1,
+    CHECK(rc == MAXSIM_OK && rc2 == MAXSIM_OK && rbb == 16 && n6 == 2 && out6[0] == 0 && out6[1] == 2 && out6[2] == -1 && out6[5] == -1,
           "embedding_ids_to_pids_ex: row blocks + id_base (the empty doc 1 owns no row)");
     rc2 = maxsim_embedding_ids_to_pids_ex((const int64_t*)dids6, 1, 6, 3, (const uint8_t*)dkeep1, 100, (const int64_t*)doffs3, 3, 5,
                                           NULL, dout6, dn6, NULL);

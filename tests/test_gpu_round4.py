@@ -51,18 +51,32 @@ def make_ranker(ca, doclens):
 
 
 def test_row_block_table(ca):
-    """maxsim_build_row_blocks: entry b = the doc of token row 64 b (empty docs skipped), last entry = n_docs - 1."""
+    """maxsim_build_row_blocks: entry b = {doc of token row 64 b (empty docs skipped), offset of the next doc inside the block
+    or 0, "search" flag}; last entry = n_docs - 1.  Decoded here against build_emb2pid for EVERY row."""
     g = torch.Generator().manual_seed(1)
     doclens = torch.randint(0, 300, (3000,), generator=g).tolist()
     doclens[100:400] = [0] * 300                       # a long run of empty docs
+    doclens[500:540] = [3] * 40                        # many docs inside one block
     doclens[-1] = 5
     r = make_ranker(ca, doclens)
     e2p = emb2pid_of(doclens)
     ntok = e2p.numel()
     nblocks = (ntok + 63) // 64
-    tbl = r.d_row_blocks.view(torch.int32)[:nblocks + 1].cpu().long()
-    assert tbl[:nblocks].tolist() == e2p[torch.arange(nblocks) * 64].tolist()
-    assert int(tbl[nblocks]) == len(doclens) - 1
+    tbl = r.d_row_blocks.view(torch.int64)[:nblocks + 1].cpu()
+    d0 = tbl & 0xFFFFFFFF
+    bnd = (tbl >> 32) & 127
+    multi = (tbl >> 39) & 1
+    assert d0[:nblocks].tolist() == e2p[torch.arange(nblocks) * 64].tolist()
+    assert int(d0[nblocks]) == len(doclens) - 1
+    rows = torch.arange(ntok)
+    b = rows >> 6
+    simple = multi[b] == 0
+    got = d0[b] + ((bnd[b] != 0) & ((rows & 63) >= bnd[b])).long()
+    assert torch.equal(got[simple], e2p[simple])       # one 8-byte entry answers these rows
+    assert int(simple.sum()) > ntok // 2 and int((~simple).sum()) > 0
+    # flagged blocks: the doc lies between this entry's and the next one's
+    nb = b[~simple]
+    assert bool(((e2p[~simple] >= d0[nb]) & (e2p[~simple] <= d0[nb + 1])).all())
 
 
 @pytest.mark.parametrize("ndocs,lo,hi,n,distinct", [
