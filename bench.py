@@ -127,7 +127,8 @@ def pmc_lookup(workload, index_dtype, fp32_mode, suffix=""):
 PMC_PASSES = (("fetch", ["FETCH_SIZE"]), ("write", ["WRITE_SIZE"]), ("sq", ["SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"]))
 # the sweep child's workloads, in launch order: (key, workload, extra_workload keywords).  "headline" is the run's own workload.
 PMC_SWEEP = (("headline", "c2", {}), ("c2_bf16x3", "c2", dict(fp32_mode="bf16x3", reuse_prev=True)),
-             ("c2_fp16", "c2", dict(index_dtype="fp16")), ("ragged", "ragged", {}), ("ragged_fp16", "ragged", dict(index_dtype="fp16")),
+             ("c2_fp16", "c2", dict(index_dtype="fp16")), ("ragged", "ragged", {}), ("ragged_bf16x3", "ragged", dict(fp32_mode="bf16x3", reuse_prev=True)),
+             ("ragged_fp16", "ragged", dict(index_dtype="fp16")),
              ("c4", "c4", {}), ("c5", "c5", {}),
              ("dep768", "dep768", {}))
 PMC_SWEEP_LAUNCHES = 4
@@ -822,18 +823,23 @@ def main():
             torch.cuda.empty_cache()
             for key, name, kw, label in (("c2_fp16", "c2", dict(index_dtype="fp16", online_call=True), "c2 with the reference's fp16 index (colbert_ranker.py:62)"),
                                          ("ragged", "ragged", {}, "ragged fp32 (doclens N(120,40) in 8..180)"),
-                                         ("ragged_bf16x3", "ragged", dict(fp32_mode="bf16x3"), "ragged fp32 index, fp32_mode=bf16x3 (opt-in; fp32-class accuracy, "
+                                         ("ragged_bf16x3", "ragged", dict(fp32_mode="bf16x3", reuse_prev=True), "ragged fp32 index, fp32_mode=bf16x3 (opt-in; fp32-class accuracy, "
                                                               "tests/test_gpu_parity.py::test_fp32_bf16x3_mode_is_fp32_accurate)"),
                                          ("ragged_fp16", "ragged", dict(index_dtype="fp16"), "ragged docs on the reference's fp16 index (doclens N(120,40) in 8..180, colbert_ranker.py:62)"),
                                          ("c4", "c4", {}, "C4 multi-view: 8 x 8 tokens (BASELINE configs[3])"),
                                          ("c5", "c5", {}, "C5 bf16 dim 768, 32 x 256 tokens (BASELINE configs[4])"),
                                          ("dep768", "dep768", dict(online_call=True), "reference default deployment: dim 768, fp16 index, doclens N(200,80) in 8..384 "
                                                               "(proj_conf/dense.yaml:6-8, encoder.py:175)")):
-                o, keep = extra_workload(colbert_amd, name, dev, xs, xw, label=label, **kw)
+                kw = dict(kw)
+                reuse = keep if kw.pop("reuse_prev", False) else None      # (the same fp32 tokens, another contraction)
+                keep = None
+                if reuse is None:
+                    torch.cuda.empty_cache()
+                o, keep = extra_workload(colbert_amd, name, dev, xs, xw, label=label, reuse=reuse, **kw)
                 o["pmc_key"] = key
                 others.append(o)
-                keep = None
-                torch.cuda.empty_cache()
+            keep = None
+            torch.cuda.empty_cache()
             if "read_ceiling" in rf:
                 for o in others:
                     o["frac_of_read_ceiling"] = round(o["achieved"] / rf["read_ceiling"]["GBps"], 4)
