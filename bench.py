@@ -461,6 +461,24 @@ def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32
         b2b = e0.elapsed_time(e1) / 20
         out["kernel_ms_back_to_back"] = round(b2b, 4)
         out["frac_back_to_back"] = round(alg / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # ... and what a bigger batch per launch reads (a launch this short pays its ramp and its one-round tail in full):
+        # 8 x the queries, same docs per query
+        nq8 = 8 * NQ
+        Q8 = F.normalize(torch.randn(nq8, lq, h, generator=gq, device=dev), dim=-1).to(Q.dtype)
+        c8 = torch.randint(0, len(doclens), (4, nq8, NCAND), generator=gc, device=dev, dtype=torch.int64)
+        for i in range(2):
+            ranker.score_candidates(Q8, c8[i])
+        e0.record()
+        for i in range(8):
+            ranker.score_candidates(Q8, c8[i % 4])
+        e1.record()
+        e1.synchronize()
+        ms8 = e0.elapsed_time(e1) / 8
+        tok8, docs8 = live_tokens(ranker, c8, 0, len(doclens), 0, 4)
+        alg8 = algorithmic_bytes(tok8, docs8, nq8, lq, h, esize, Q.element_size())
+        out["batch_x8"] = {"queries_per_launch": nq8, "kernel_ms_back_to_back": round(ms8, 4),
+                           "frac": round(alg8 / (ms8 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        del Q8, c8
     if online_call:     # the reference's online call on this index (its storage dtype): one rank_forward per query
         out["single_query"] = single_query_probe(ranker, Q, cands, h, lq, esize)
         if wl["ragged"] is None and h == 128 and online_call != "only":
