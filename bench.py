@@ -582,6 +582,46 @@ def sharded_from_files_check(colbert_amd, dev, rank, world, one_gpu):
             "shard_of_rank0": [sh.lo, sh.hi], "strides": list(sh.local.strides)}
 
 
+def sharded_retrieve_step(sharded, ranker, Q, dev, world, doclens, steps=6, faiss_depth=512, hot=1500):
+    """N > 1 only, labelled extra (not `value`): the doc-sharded batched driver's step after the ANN search over the job's
+    process group -- every rank gets the same 256 x world queries and the same GLOBAL token rows (32 tokens x faiss_depth
+    synthetic ANN ids per query that cluster on ~1500 docs drawn over ALL shards; uniform docs, so row = pid * L + t), keeps
+    the rows inside its token range (`id_base`), reranks its distinct docs (counted rows), takes a counted local top-100, the
+    ONE all_gather, merge: ShardedRanker.local_retrieve_topk + all_gather_topk + merge_gathered, as
+    ShardedRanker.retrieve_batch runs them, minus the final copy to python lists.  Wall time per step, max over ranks."""
+    from colbert_amd.sharded import all_gather_topk, merge_gathered
+    L = int(doclens[0])
+    if any(int(x) != L for x in doclens[:1000]):
+        return {"skipped": "needs a uniform index (row = pid * L + t)"}
+    nq, lq = Q.size(0), Q.size(1)
+    n = lq * faiss_depth
+    nd_total = world * len(doclens)
+    g = torch.Generator(device=dev).manual_seed(7)
+    docs = torch.randint(0, nd_total, (nq, hot), generator=g, device=dev)
+    ids = docs.gather(1, torch.randint(0, hot, (nq, n), generator=g, device=dev)) * L + torch.randint(0, L, (nq, n), generator=g, device=dev)
+    keep = torch.ones(nq, lq, dtype=torch.bool, device=dev)
+
+    def step():
+        top_p, top_s = sharded.local_retrieve_topk(Q, keep, ids, TOPK)
+        gs, gp = all_gather_topk(top_s, top_p, world, sharded.group)
+        return merge_gathered(gs, gp, TOPK, sharded.topk_fn)
+    for _ in range(2):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = step()
+    torch.cuda.synchronize()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=out[0].device if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ms = float(el.item()) / steps * 1e3
+    found = int((out[0] >= 0).sum().item())
+    return {"shape": f"{nq} queries x {n} GLOBAL ANN token rows over {nd_total} docs, ~{hot} distinct docs per query over all {world} shards",
+            "ms_per_step": round(ms, 4), "queries_per_s": round(nq / (ms * 1e-3), 1), "steps": steps,
+            "merged_top_entries_found": found, "expected": nq * TOPK}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -782,6 +822,12 @@ def main():
             files_check = sharded_from_files_check(colbert_amd, dev, rank, world, one_gpu)
         except Exception as e:        # a failed self-check is reported in the line, it must not lose the measurement
             files_check = {"error": f"{type(e).__name__}: {e}"}
+    shard_retrieve = None
+    if use_dist and world > 1 and not sim:
+        try:
+            shard_retrieve = sharded_retrieve_step(sharded, ranker, Q, dev, world, doclens)
+        except Exception as e:
+            shard_retrieve = {"error": f"{type(e).__name__}: {e}"}
 
     default_shape = ndocs == wl["ndocs"] and not (args.lq or args.nq or args.ncand or args.ld or args.q_dtype) and (world == 1)
     suffix = f"_shard{job_world}" if sim else ""
@@ -818,6 +864,7 @@ def main():
             res["backend"] = dist.get_backend()
             res["per_rank"] = per_rank
             res["sharded_from_files"] = files_check
+            res["sharded_retrieve_step"] = shard_retrieve
         if strat is not None:
             res["stratified"] = strat
         full = world == 1 and args.workload == "c2" and not args.no_cpu_baseline and not sim and default_shape
