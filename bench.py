@@ -991,7 +991,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     list in, python lists out, host-synchronous -- latency, not throughput.  `gpu_span_ms` is the time between two HIP
     events recorded on the launch stream right before and after the call (both kernels + the gap between them);
     `host_ms` = end-to-end minus that span (the events themselves add a few us to the span: the kernel's own duration is
-    in profiles/r03_single_query_*)."""
+    in profiles/r04_single_query_*)."""
     Q1 = Q[:1].float().permute(0, 2, 1)     # [1, h, Lq]: the permuted VIEW of a [1, Lq, h] tensor, as faiss_indexers.py:232-233 hands it over
     out = {"call": "rank_forward(Q[1,h,Lq], 1000 pids, depth=100) -> python lists"}
     lat, span = [], []
@@ -1021,7 +1021,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     out.update({"median_ms": round(med, 4), "min_ms": round(lat[0] * 1e3, 4), "gpu_span_ms": round(gspan, 4),
                 "host_ms": round(max(med - gspan, 0.0), 4), "queries_per_s_sequential": round(1e3 / med, 1),
                 "algorithmic_GBps_over_gpu_span": round((ntok * H * esize + LQ * H * 4) / (gspan * 1e-3) / 1e9, 1),
-                "kernel_profile": "profiles/r03_single_query_summary.json"})
+                "kernel_profile": "profiles/r04_single_query_summary.json"})
     # 16 queries per launch (a small server batch): the rerank kernel alone, 20 launches back to back between two events
     ks = []
     for rep in range(5):
