@@ -245,3 +245,44 @@ def test_backward_with_skewed_argmax_buckets(ca, dtype, atol, nq):
     assert float(gd1[3].abs().max()) == 0.0 and float(gd1[0, 1:].abs().max()) == 0.0
     o3, gq3, gd3 = run(ca.score, Qt, Dt)
     assert torch.equal(gd1, gd3) and torch.equal(gq1, gq3)
+
+
+@pytest.mark.parametrize("h,dtype,lo,hi,gib", [(128, torch.float16, 40, 180, 4.6), (128, torch.float32, 8, 8, 4.4),
+                                               (768, torch.float16, 100, 300, 4.5), (128, torch.float32, 60, 180, 4.4)])
+def test_candidates_beyond_4_gib_of_index(ca, h, dtype, lo, hi, gib):
+    """Byte offsets past 2^32: an index of > 4 GiB per kernel family (h = 128 16-bit ragged, the fixed-length fp32 kernel,
+    the LDS-query kernel at dim 768, h = 128 fp32 ragged), candidates drawn from its LAST docs, against the float64 closed form
+    on the gathered rows (oracle.ragged_scores_f64); rank_forward and the counted form on the same rows."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    dev = "cuda"
+    esz = 2 if dtype == torch.float16 else 4
+    ntok_target = int(gib * (1 << 30) / (h * esz))
+    g = torch.Generator().manual_seed(h + lo)
+    ndocs = ntok_target // ((lo + hi) // 2)
+    doclens = torch.randint(lo, hi + 1, (ndocs,), generator=g).tolist()
+    ntok = sum(doclens)
+    gd = torch.Generator(device=dev).manual_seed(7)
+    idx = torch.empty(ntok, h, dtype=dtype, device=dev)
+    step = 1 << 22
+    for s in range(0, ntok, step):
+        e = min(s + step, ntok)
+        idx[s:e] = F.normalize(torch.randn(e - s, h, generator=gd, device=dev), dim=-1).to(dtype)
+    assert idx.numel() * esz > (1 << 32)
+    r = ca.ColbertRanker.from_device_tensor(idx, doclens)
+    nq, ncand, Lq = 3, 40, 32 if lo > 8 else 8
+    Q = F.normalize(torch.randn(nq, Lq, h, generator=g), dim=-1)
+    cand = torch.randint(ndocs - 400, ndocs, (nq, ncand), generator=g)                 # the tail of the index: offsets > 4 GiB
+    assert int(r.doclens_pfxsum[ndocs - 400]) * h * esz > (1 << 32)
+    got = r.score_candidates(Q.cuda(), cand.cuda()).cpu()
+    cnt = torch.full((nq,), ncand, dtype=torch.int32)
+    got_c = r.score_candidates(Q.cuda(), cand.cuda(), cand_count=cnt.cuda()).cpu()
+    assert torch.equal(got, got_c)
+    offs, pad = r.doclens_pfxsum, r.d_pad_len.cpu()
+    rows_lo = int(offs[ndocs - 400])
+    tail = idx[rows_lo:].cpu()                                                           # ~1 % of the index
+    for q in range(nq):
+        exp = ragged_scores_f64(tail, doclens, (offs[:-1] - rows_lo).tolist(), pad.tolist(), Q[q], cand[q].tolist())
+        np.testing.assert_allclose(got[q].numpy(), exp, rtol=0, atol=1e-3 if dtype == torch.float16 else 1e-4)
+    p, s = r.rank_forward(Q[:1].cuda().permute(0, 2, 1), cand[0].tolist(), depth=5)
+    order = np.argsort(-got[0].numpy(), kind="stable")[:5]
+    assert s == got[0].numpy()[order].tolist() and p == cand[0][order].tolist()
