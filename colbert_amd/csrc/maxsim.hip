@@ -277,8 +277,8 @@ static int rerank_impl(const maxsim_index_view& iv, const void* Q, int q_dtype, 
     const int D0 = stream_list_docs_per_item(p);
     int32_t* const wl = (int32_t*)worklist;
     // (wave slots the list kernel keeps resident: 2 workgroups of 4 waves per CU; the fixed-length short-doc kernel 4)
-    const bool uni_short = index_dtype == MAXSIM_F32 && p.n_tokens <= 24 * p.n_docs && p.n_tokens == (int64_t)p.uniform_len * p.n_docs &&
-                           (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16);
+    const bool uni_short = (index_dtype == MAXSIM_F32 || index_dtype == MAXSIM_F16 || index_dtype == MAXSIM_BF16) &&
+                           p.n_tokens == (int64_t)p.uniform_len * p.n_docs && (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16);
     const int slots_knob = MAXSIM_KNOB("MAXSIM_LIST_SLOTS", -1);  // (diagnostic builds: 0 switches the one-round rule off)
     const int list_slots = slots_knob >= 0 ? slots_knob : (uni_short ? 4096 : 2048);
     if (nq <= LIST_FUSED_FILL_NQ) {  // a handful of rows: scan + fill in one launch

@@ -524,6 +524,49 @@ struct ReducerArg {
   }
 };
 
+// Eight consecutive query dims -> the index type's NP 16-bit pieces, packed in pairs (what a lane holds per MFMA k-group):
+//   fp16 / fp32-fast  x = hi + 2^-11 lo (two fp16 pieces)
+//   bf16              x = b0 + b1 + b2 (round-to-nearest pieces: 24 significant bits in all)
+//   fp32 as 3 x bf16  x = t0 + t1 + t2 exactly (truncation pieces)
+template <int DT>
+__device__ __forceinline__ void q_split_pack(const float (&q)[8], u32x4 (&w)[DT == MAXSIM_F32 ? 1 : StreamTraits<DT>::NP]) {
+  constexpr int NP = StreamTraits<DT>::NP;
+  constexpr bool F16Q = (DT == MAXSIM_F16 || DT == F32S);
+  uint16_t pc[DT == MAXSIM_F32 ? 1 : NP][8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = q[j];
+    if constexpr (DT == MAXSIM_F32) {
+      pc[0][j] = 0;
+    } else if constexpr (DT == F32X) {  // exact truncation split: x = t0 + t1 + t2
+      const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
+      const float r1 = x - __uint_as_float(u0);
+      const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
+      const float r2 = r1 - __uint_as_float(u1);
+      pc[0][j] = (uint16_t)(u0 >> 16);
+      pc[1][j] = (uint16_t)(u1 >> 16);
+      pc[NP - 1][j] = (uint16_t)(__float_as_uint(r2) >> 16);
+    } else if constexpr (F16Q) {
+      _Float16 hi = (_Float16)x;
+      _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
+      __builtin_memcpy(&pc[0][j], &hi, 2);
+      __builtin_memcpy(&pc[1][j], &lo, 2);
+    } else {
+      uint16_t b0 = f32_to_bf16_rn(x);
+      float r1 = x - bf16_to_f32(b0);
+      uint16_t b1 = f32_to_bf16_rn(r1);
+      float r2 = r1 - bf16_to_f32(b1);
+      pc[0][j] = b0;
+      pc[1][j] = b1;
+      pc[NP - 1][j] = f32_to_bf16_rn(r2);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < (DT == MAXSIM_F32 ? 1 : NP); ++k)
+#pragma unroll
+    for (int y = 0; y < 4; ++y) w[k][y] = (uint32_t)pc[k][2 * y] | ((uint32_t)pc[k][2 * y + 1] << 16);
+}
+
 constexpr int QT_2X16 = 48;  // 32 query tokens as two 16-column blocks of v_mfma_f32_16x16x4_f32
 // QT = 16: at most 16 query tokens (e.g. the multi-view configs, dense.yaml q_view): fp32 index on
 // v_mfma_f32_16x16x4_f32 -- half the matrix-pipe time of the 32-column form, half the query registers.
@@ -636,39 +679,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   constexpr bool F16Q = (DT == MAXSIM_F16 || DT == F32S);  // query split into fp16 hi + 2^-11 lo
   // eight consecutive query dims -> this index type's NP 16-bit pieces, packed in pairs (what a lane holds per k-group)
   auto split_pack = [&](const float (&q)[8], u32x4 (&w)[DT == MAXSIM_F32 ? 1 : NP]) __attribute__((always_inline)) {
-    uint16_t pc[DT == MAXSIM_F32 ? 1 : NP][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = q[j];
-      if constexpr (DT == MAXSIM_F32) {
-        pc[0][j] = 0;
-      } else if constexpr (DT == F32X) {  // exact truncation split: x = t0 + t1 + t2
-        const uint32_t u0 = __float_as_uint(x) & 0xffff0000u;
-        const float r1 = x - __uint_as_float(u0);
-        const uint32_t u1 = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(u1);
-        pc[0][j] = (uint16_t)(u0 >> 16);
-        pc[1][j] = (uint16_t)(u1 >> 16);
-        pc[NP - 1][j] = (uint16_t)(__float_as_uint(r2) >> 16);
-      } else if constexpr (F16Q) {
-        _Float16 hi = (_Float16)x;
-        _Float16 lo = (_Float16)((x - (float)hi) * 2048.0f);
-        __builtin_memcpy(&pc[0][j], &hi, 2);
-        __builtin_memcpy(&pc[1][j], &lo, 2);
-      } else {
-        uint16_t b0 = f32_to_bf16_rn(x);
-        float r1 = x - bf16_to_f32(b0);
-        uint16_t b1 = f32_to_bf16_rn(r1);
-        float r2 = r1 - bf16_to_f32(b1);
-        pc[0][j] = b0;
-        pc[1][j] = b1;
-        pc[NP - 1][j] = f32_to_bf16_rn(r2);
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < (DT == MAXSIM_F32 ? 1 : NP); ++k)
-#pragma unroll
-      for (int y = 0; y < 4; ++y) w[k][y] = (uint32_t)pc[k][2 * y] | ((uint32_t)pc[k][2 * y + 1] << 16);
+    q_split_pack<DT>(q, w);
   };
   if constexpr (QSTAGE) {
     int qlen0 = p.Lq;
@@ -1494,6 +1505,180 @@ __global__ void __launch_bounds__(WAVES * 64, NCB == 1 ? (LIST ? 4 : 5) : 3) k_m
       float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tree[0]), d * (64 / DPT)));
       if constexpr (NCB == 2) sc += __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tree[1]), d * (64 / DPT)));
       myscore = (lane == t * DPT + d) ? sc : myscore;
+    }
+  }
+  if (lane < ndoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + (bad ? NEG_INF : myscore);
+  };  // wave_item
+  if constexpr (LIST) {  // (slot -> item as in k_maxsim_stream's list form: XCD x walks the x-th eighth of the list)
+    const int32_t* const wl = (const int32_t*)p.worklist;
+    const int wl_total = uni(wl[0]);
+    const int2* const wl_items = (const int2*)(wl + worklist_items_word(p.nq));
+    const int J = (wl_total + WAVES - 1) / WAVES, Jx = (J + 7) >> 3;
+    for (int s = (int)blockIdx.x; s < 8 * Jx; s += (int)gridDim.x) {
+      const int item = ((s & 7) * Jx + (s >> 3)) * WAVES + wave;
+      if ((s >> 3) >= Jx || item >= wl_total) continue;
+      const int2 e = wl_items[item];
+      wave_item(uni(e.x), uni(e.y) & ((1 << WL_SLOT_BITS) - 1), uni(e.y) >> WL_SLOT_BITS);
+    }
+  } else {
+    int qi, chunk;
+    wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
+    const int dpwv = p.dpw / WAVES;
+    const int c_begin = chunk * p.dpw + wave * dpwv;
+    wave_item(qi, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Uniform short docs on a 16-BIT index: the reference stores fp16 (colbert_ranker.py:62, encoder.py:175), so its multi-view
+// deployments (proj_conf/dense.yaml:29-32: every doc keeps d_view viewer tokens) are exactly this -- every doc L = 4, 8 or
+// 16 rows of 256 bytes.  Through the general kernel such a launch is instruction-bound (a packed 32-row tile holds 2-8
+// docs: cursor walk, per-slot row gathers, masked maxima and one finish per doc next to 16 short MFMAs: 0.51 of the HBM
+// peak at 256 x 1000 eight-token docs).  With L compiled in, as in k_maxsim_stream_uni: a tile is DPT = 32 / L whole docs,
+// the source address of DMA instruction i is a scalar base + ONE xor on a per-lane constant (its 4 rows lie in one doc
+// since 4 | L), and the DPB = 16 / L docs of a 16-row block finish together.  Contraction, piece split, k-order, 2^-11
+// scaling and sum tree are the general 16-bit kernel's (v_mfma_f32_16x16x32, Q = Qhi + 2^-11 Qlo / three bf16 pieces):
+// scores are bit-identical to k_maxsim_stream<RERANK, DT, .., QT_2X16>.  NT tiles of 8 KiB per wave in the ring.
+template <int DT, int WAVES, int NCB, int L, int NT, bool LIST = false>
+__global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_uni16(KARGS_DECL) {
+  static_assert(DT == MAXSIM_F16 || DT == MAXSIM_BF16, "16-bit index types");
+  static_assert(L == 4 || L == 8 || L == 16, "uniform doc length: 4, 8 or 16 tokens");
+  static_assert(NT == 1 || NT == 2, "one or two tiles per wave in flight");
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  KARGS_TO_PARAMS;
+  constexpr int ROWB = 256, TILE = 32 * ROWB, NDMA = 8, DPT = 32 / L, DPB = 16 / L, NP = StreamTraits<DT>::NP;
+  const int lane = threadIdx.x & 63;
+  const int wave = uni(threadIdx.x >> 6);
+  auto wave_item = [&](const int qi, const int c_begin, const int ndoc) __attribute__((always_inline)) {
+  if (ndoc == 0) return;
+  float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
+  const int n16 = lane & 15, kq = lane >> 4;
+  // ---- query -> registers first (its loads and the pid load below are in flight together; the piece split runs under the
+  //      first tile's fetch): lane (n16, kq) holds dims 8 (4 j + kq) .. + 7 of token 16 cb + n16 in qp[piece][4 cb + j]
+  u32x4 qp[NP][4 * NCB];
+  {
+    int qlen = p.Lq;
+    if (p.q_len) qlen = min(qlen, p.q_len[qi]);
+    const bool qf32 = p.q_dtype == MAXSIM_F32;
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int qt = p.q_tok0 + 16 * cb + n16;
+      const bool live = q_token_live<MODE_RERANK>(p, qi, qt, qlen);
+      const int64_t qo = ((int64_t)qi * p.Lq + (live ? qt : 0)) * 128;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int64_t e0 = qo + 8 * (4 * j + kq);
+        float q[8];
+        if (qf32) {
+          const f32x4 v0 = *(const f32x4*)((const float*)p.Q + e0), v1 = *(const f32x4*)((const float*)p.Q + e0 + 4);
+#pragma unroll
+          for (int x = 0; x < 4; ++x) { q[x] = v0[x]; q[4 + x] = v1[x]; }
+        } else {
+#pragma unroll
+          for (int x = 0; x < 8; ++x) q[x] = load_q(p.Q, p.q_dtype, e0 + x);
+        }
+#pragma unroll
+        for (int x = 0; x < 8; ++x) q[x] = live ? q[x] : 0.0f;
+        u32x4 w[NP];
+        q_split_pack<DT>(q, w);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) qp[k][4 * cb + j] = w[k];
+      }
+    }
+  }
+  // ---- descriptor lanes: lane j = first token row of the wave's j-th doc (row = pid * L: no descriptor lookup) ---------
+  uint32_t row0 = 0;
+  bool bad = true;
+  if (lane < ndoc) {
+    const int64_t pid = p.cand[(int64_t)qi * p.ncand + c_begin + lane];
+    const bool ok = pid >= 0 && pid < p.n_docs && (pid + 1) * L <= p.n_tokens;
+    row0 = ok ? (uint32_t)(pid * L) : 0u;
+    bad = !ok;
+  }
+  char* const wlds = lds + wave * (NT * TILE);
+  const char* const tok = (const char*)p.index;
+  const int ntile = (ndoc + DPT - 1) / DPT;
+  // DMA instruction i moves tile rows 4 i + (lane >> 4); chunk position c of row s receives source chunk c ^ (s & 15):
+  // per lane  off_i = ds0 * 256 + 16 * ((dch ^ ds0) ^ (4 i & 15)) = lane_off ^ ((i & 3) << 6)     (ds0 < 4: no carry into 4 i)
+  const uint32_t lane_off = (uint32_t)((lane >> 4) * ROWB + 16 * ((lane & 15) ^ (lane >> 4)));
+  auto issue = [&](int t, int buf) __attribute__((always_inline)) {
+    uint32_t base[DPT];
+#pragma unroll
+    for (int d = 0; d < DPT; ++d) base[d] = (uint32_t)__builtin_amdgcn_readlane((int)row0, min(t * DPT + d, ndoc - 1));
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+      const char* const g = tok + (uint64_t)(base[(4 * i) / L] + (uint32_t)((4 * i) % L)) * ROWB;
+      __builtin_amdgcn_global_load_lds(GPTR(g + (lane_off ^ (uint32_t)((i & 3) << 6))), LPTR(wlds + buf * TILE + i * 1024), 16, 0, CPOL_STREAM);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+    if (j < ntile) issue(j, j);
+  float myscore = 0.0f;
+  int buf = 0;
+  for (int t = 0; t < ntile; ++t) {
+    __builtin_amdgcn_s_setprio(0);
+    // tiles t + 1 .. t + NT - 1 were issued after this one (when they exist)
+    if (NT == 2 && t + 1 < ntile) wait_vmcnt<NDMA>(); else wait_vmcnt<0>();
+    // operand (row block b, k group j): row 16 b + n16, chunk 4 j + kq
+    u32x4 a[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = *(const u32x4*)(wlds + buf * TILE + (16 * (i >> 2) + n16) * ROWB + 16 * ((4 * (i & 3) + kq) ^ n16));
+    wait_lgkmcnt0();
+    if (t + NT < ntile) issue(t + NT, buf);
+    buf = (NT == 1 || buf == 1) ? 0 : 1;
+    __builtin_amdgcn_s_setprio(3);
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x4 acc0[NCB], acc1[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) acc0[cb] = acc1[cb] = (f32x4)(0.0f);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) {
+          if constexpr (DT == MAXSIM_F16) {
+            const f16x8 av = __builtin_bit_cast(f16x8, a[4 * b + j]);
+            acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, qp[0][4 * cb + j]), acc0[cb], 0, 0, 0);
+            acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av, __builtin_bit_cast(f16x8, qp[1][4 * cb + j]), acc1[cb], 0, 0, 0);
+          } else {
+            const bf16x8 av = __builtin_bit_cast(bf16x8, a[4 * b + j]);
+            acc0[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, qp[0][4 * cb + j]), acc0[cb], 0, 0, 0);
+            acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, qp[1][4 * cb + j]), acc1[cb], 0, 0, 0);
+            acc1[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, __builtin_bit_cast(bf16x8, qp[NP - 1][4 * cb + j]), acc1[cb], 0, 0, 0);
+          }
+        }
+      // similarity of query token 16 cb + n16 with tile row 16 b + 4 kq + v; doc d of the block = rows [d L, (d + 1) L)
+      float tree[NCB];
+#pragma unroll
+      for (int cb = 0; cb < NCB; ++cb) {
+        float sv[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) sv[v] = (DT == MAXSIM_F16) ? fmaf(acc1[cb][v], 1.0f / 2048.0f, acc0[cb][v]) : (acc0[cb][v] + acc1[cb][v]);
+        float m = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3]));  // the quarter's 4 rows
+        if constexpr (L >= 8) {  // quarters g, g + 1
+          const uint32_t xb = __float_as_uint(m);
+          const auto s16 = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+          m = fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1]));
+        }
+        if constexpr (L == 16) {  // quarters g, g + 2
+          const uint32_t xb = __float_as_uint(m);
+          const auto s32 = __builtin_amdgcn_permlane32_swap(xb, xb, false, false);
+          m = fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1]));
+        }
+        m += dpp_f32<0xB1>(m);  // the general kernels' pairwise tree over the block's 16 query-token lanes
+        m += dpp_f32<0x4E>(m);
+        m += dpp_f32<0x141>(m);
+        m += dpp_f32<0x140>(m);
+        tree[cb] = m;
+      }
+#pragma unroll
+      for (int d = 0; d < DPB; ++d) {  // doc d's sums sit in the 16-lane row that holds its rows: lane d * (64 / DPB)
+        float sc = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tree[0]), d * (64 / DPB)));
+        // (one block: the general kernel adds the all-zero second block's +0.0 -- kept, so that even a -0.0 sum agrees)
+        sc += (NCB == 2) ? __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(tree[NCB - 1]), d * (64 / DPB))) : 0.0f;
+        myscore = (lane == t * DPT + b * DPB + d) ? sc : myscore;
+      }
     }
   }
   if (lane < ndoc) srow[lane] = (p.accum ? srow[lane] : 0.0f) + (bad ? NEG_INF : myscore);

@@ -62,6 +62,38 @@ int launch_stream_uni_l(Params& p, bool many, hipStream_t st) {
   return p.Lq <= 16 ? launch_stream_uni<4, 1, L>(p, st) : launch_stream_uni<4, 2, L>(p, st);
 }
 
+// the same for a 16-bit index (the reference's storage dtype): k_maxsim_stream_uni16, NT tiles of 8 KiB per wave
+template <int DT, int WAVES, int NCB, int L, int NT>
+int launch_stream_uni16(Params& p, hipStream_t st) {
+  int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);
+  if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, WAVES);
+  p.dpw = dpwv * WAVES;
+  p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+  const int ldsb = WAVES * NT * 8192;
+  auto kern = k_maxsim_stream_uni16<DT, WAVES, NCB, L, NT>;
+  int rc = allow_lds(kern, ldsb);
+  if (rc) return rc;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  return check_launch();
+}
+template <int DT, int L>
+int launch_stream_uni16_l(Params& p, hipStream_t st) {
+  // Workgroups of 8 waves when there are enough of them to fill the chip (fewer dispatches), of 4 waves otherwise; one 8 KiB
+  // tile per wave in the ring.  Measured at 256 / 2048 queries x 1000 eight-token fp16 docs (tools/probe_multiview.py): 8 x 1
+  // 0.788 / 0.827 of the HBM peak, 4 x 1 0.791 / 0.830, 4 waves x 2 tiles 0.802 / 0.831 -- no shape matters; the general kernel
+  // 0.511 / 0.624.  (diagnostic: MAXSIM_UNI16_SHAPE = 1 / 2 forces 8 x 1 / 4 x 1)
+  const int shape = MAXSIM_KNOB("MAXSIM_UNI16_SHAPE", 0);
+  const bool many = (int64_t)p.nq * ((p.ncand + 511) / 512) >= 256;
+  const int pick = shape ? shape : (many ? 1 : 2);
+  if (pick == 2) return p.Lq <= 16 ? launch_stream_uni16<DT, 4, 1, L, 1>(p, st) : launch_stream_uni16<DT, 4, 2, L, 1>(p, st);
+  return p.Lq <= 16 ? launch_stream_uni16<DT, 8, 1, L, 1>(p, st) : launch_stream_uni16<DT, 8, 2, L, 1>(p, st);
+}
+// every doc of the index exactly 4 / 8 / 16 tokens and none padded (maxsim_index_view.uniform_len): that length, else 0
+inline int uniform_short_len(const Params& p) {
+  const int L = p.uniform_len;
+  return (p.n_docs > 0 && (L == 4 || L == 8 || L == 16) && p.n_tokens == (int64_t)L * p.n_docs) ? L : 0;
+}
+
 // Per-wave LDS ring: fp32 1 x 16 KiB tile, 16-bit 2 x 8 KiB tiles; 4 waves per workgroup = 64 KiB, two
 // workgroups per CU.  MAXSIM_VARIANT exists in diagnostic builds only (-DMAXSIM_DIAG; DESIGN.md "Tuning knobs"):
 // 1/2 = ablation kernels (timing only, WRONG scores) -- the shipped library does not even contain them.
@@ -113,6 +145,19 @@ int launch_stream(Params& p, hipStream_t st) {
 #endif
       return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
   }
+  if constexpr (MODE == MODE_RERANK && (DT == MAXSIM_F16 || DT == MAXSIM_BF16)) {
+    // a 16-bit index whose every doc has the same 4 / 8 / 16 tokens (the reference's multi-view deployments: fp16 storage,
+    // colbert_ranker.py:62, d_view viewer tokens per doc, dense.yaml:29-32): the kernel with the length compiled in
+    // (diagnostic: MAXSIM_VARIANT != 0 keeps the general kernel)
+    if (variant == 0) {
+      switch (uniform_short_len(p)) {
+        case 8: return launch_stream_uni16_l<DT, 8>(p, st);
+        case 4: return launch_stream_uni16_l<DT, 4>(p, st);
+        case 16: return launch_stream_uni16_l<DT, 16>(p, st);
+        default: break;
+      }
+    }
+  }
   if constexpr (MODE == MODE_RERANK && DT != MAXSIM_F32 && DT != MAXSIM_F32_FAST) {
     // 16-bit index and the 3 x bf16 mode of an fp32 index: v_mfma_f32_16x16x32 in two 16-column blocks (+2-3 %: a
     // higher sustained clock than 32x32x16 on the power cap; the fp16-split fast mode measured 1 % slower in this form
@@ -163,6 +208,23 @@ int launch_list_v(Params& p, int max_wgs, hipStream_t st) {
 }  // namespace
 
 namespace {
+template <int DT, int L>
+int launch_list_uni16(Params& p, int wgs, hipStream_t st) {
+  constexpr int WAVES = 4;
+  const int ldsb = WAVES * 8192;
+  if (p.Lq <= 16) {
+    hipLaunchKernelGGL((k_maxsim_stream_uni16<DT, WAVES, 1, L, 1, true>), dim3((unsigned)wgs), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  } else {
+    hipLaunchKernelGGL((k_maxsim_stream_uni16<DT, WAVES, 2, L, 1, true>), dim3((unsigned)wgs), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+  }
+  return check_launch();
+}
+template <int DT>
+int launch_list_uni16_dt(Params& p, int L, int wgs, hipStream_t st) {
+  if (L == 8) return launch_list_uni16<DT, 8>(p, wgs, st);
+  if (L == 4) return launch_list_uni16<DT, 4>(p, wgs, st);
+  return launch_list_uni16<DT, 16>(p, wgs, st);
+}
 template <int L>
 int launch_list_uni(Params& p, int wgs, hipStream_t st) {
   constexpr int WAVES = 4;
@@ -200,11 +262,14 @@ int launch_stream_list(Params& p, int index_dtype, int64_t max_items, hipStream_
   if (wgs < 1) wgs = 1;
   if (wgs > cap) wgs = cap;
   wgs = (wgs + 7) & ~(int64_t)7;  // the kernel's slot -> item map assumes a workgroup's slots share s % 8
-  if (p.n_docs > 0 && p.n_tokens <= 24 * p.n_docs && index_dtype == MAXSIM_F32 && p.n_tokens == (int64_t)p.uniform_len * p.n_docs &&
-      (p.uniform_len == 4 || p.uniform_len == 8 || p.uniform_len == 16)) {  // a uniform short-doc fp32 index
-    if (p.uniform_len == 8) return launch_list_uni<8>(p, (int)wgs, st);
-    if (p.uniform_len == 4) return launch_list_uni<4>(p, (int)wgs, st);
-    return launch_list_uni<16>(p, (int)wgs, st);
+  if (const int L = uniform_short_len(p); L != 0) {  // a uniform short-doc index: the fixed-length kernels
+    if (index_dtype == MAXSIM_F16) return launch_list_uni16_dt<MAXSIM_F16>(p, L, (int)wgs, st);
+    if (index_dtype == MAXSIM_BF16) return launch_list_uni16_dt<MAXSIM_BF16>(p, L, (int)wgs, st);
+    if (index_dtype == MAXSIM_F32) {
+      if (L == 8) return launch_list_uni<8>(p, (int)wgs, st);
+      if (L == 4) return launch_list_uni<4>(p, (int)wgs, st);
+      return launch_list_uni<16>(p, (int)wgs, st);
+    }
   }
   if (p.Lq <= 16 && index_dtype == MAXSIM_F32) return launch_list_v<MAXSIM_F32, 16>(p, (int)wgs, st);
   switch (index_dtype) {

@@ -1,0 +1,175 @@
+"""GPU parity tests added in round 5: the reference's multi-view deployment shapes in its own storage dtype
+(proj_conf/dense.yaml:8,29-32: dim 768, q_view = d_view = 16; BaseModel.py:21-24 keeps the first `view` tokens;
+colbert_ranker.py:62 stores fp16) -- the fixed-length 16-bit kernel k_maxsim_stream_uni16 for dim 128 and the LDS-query
+kernel for dim 768.  Tolerances as in test_gpu_parity.py: 16-bit inputs |d| <= 1e-3 against the oracle on identically
+rounded inputs; kernel forms against each other: bit for bit."""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ATOL16 = 1e-3
+
+
+@pytest.fixture(scope="module")
+def ca():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    import colbert_amd
+    return colbert_amd
+
+
+def nrm(gen, *shape):
+    return F.normalize(torch.randn(*shape, generator=gen), dim=-1)
+
+
+def without_promise(r):
+    """The same index with the fixed-length promise withdrawn (uniform_len = 0): the library takes its general kernels."""
+    g = copy.copy(r)
+    g._iv = r._index_view()
+    g._iv.uniform_len = 0
+    g._iv_ref = ctypes.byref(g._iv)
+    g._iv_addr = ctypes.addressof(g._iv)
+    return g
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("L,Lq", [(8, 8), (8, 32), (4, 7), (4, 20), (16, 16), (16, 40), (8, 1)])
+def test_uniform_short_docs_16bit_kernel_is_bit_identical(ca, dtype, L, Lq):
+    """A 16-bit index whose every doc has exactly L tokens runs k_maxsim_stream_uni16 (doc length compiled in); its scores
+    equal, bit for bit, those of the general packed-tile kernel on the same index (the promise withdrawn) and agree with the
+    oracle's closed form on the identically rounded values: padding slots, out-of-range pids, row widths that leave the last
+    tile / wave / workgroup partly filled, q_mask, q_len, fp32 and 16-bit queries, queries longer than 32 tokens."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(500 + L + Lq)
+    ndocs, h = 5000, 128
+    doclens = [L] * ndocs
+    emb = nrm(gen, sum(doclens), h).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=dtype)
+    assert r._iv.uniform_len == L
+    g = without_promise(r)
+    for nq, ncand in ((1, 1), (3, 7), (2, 65), (5, 1000), (300, 130), (2, 2049), (70, 513)):
+        Q = nrm(gen, nq, Lq, h)
+        cand = torch.randint(0, ndocs, (nq, ncand), generator=gen)
+        if ncand > 3:
+            cand[0, 1] = -1                              # padding slot
+            cand[-1, ncand - 2] = ndocs + 3              # out of range
+        qm = (torch.rand(nq, Lq, generator=gen) > 0.25).long()
+        qm[:, 0] = 1
+        ql = torch.randint(1, Lq + 1, (nq,), generator=gen)
+        for kw in (dict(), dict(q_mask=qm), dict(q_len=ql)):
+            for Qx in (Q, Q.to(dtype)):
+                a = r.score_candidates(Qx, cand.cuda(), **kw).cpu()
+                b = g.score_candidates(Qx, cand.cuda(), **kw).cpu()
+                assert torch.equal(a, b), (L, Lq, nq, ncand, list(kw), Qx.dtype)
+        a = r.score_candidates(Q, cand.cuda(), q_mask=qm).cpu()
+        if ncand > 3:
+            assert float(a[0, 1]) == float("-inf") and float(a[-1, ncand - 2]) == float("-inf")
+        if nq <= 5 and ncand <= 1000:
+            for qi in range(nq):
+                ok = [(c, p) for c, p in enumerate(cand[qi].tolist()) if 0 <= p < ndocs][:40]
+                exp = ragged_scores_f64(emb.float(), r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi][qm[qi].bool()], [p for _, p in ok])
+                np.testing.assert_allclose(a[qi, [c for c, _ in ok]].numpy(), exp, rtol=0, atol=ATOL16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("L,Lq,nq,ncand", [(8, 8, 40, 500), (16, 40, 9, 130), (4, 20, 12, 300), (8, 32, 3, 2100)])
+def test_uniform_16bit_counted_rows_equal_full_width_rows(ca, dtype, L, Lq, nq, ncand):
+    """Counted rows (a doc shard's share / ANN pid lists) of a uniform 16-bit index walk the device-built work list with the
+    LIST form of k_maxsim_stream_uni16: same bits as the static grid on the same rows, and as the general kernels."""
+    gen = torch.Generator().manual_seed(77 + L)
+    ndocs, h = 3000, 128
+    emb = nrm(gen, ndocs * L, h).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[[L] * ndocs], dim=h, index_dtype=dtype)
+    g = without_promise(r)
+    counts = torch.randint(0, ncand + 1, (nq,), generator=gen)
+    counts[0], counts[-1] = 0, ncand
+    cand = torch.full((nq, ncand), -1, dtype=torch.int64)
+    for q in range(nq):
+        cand[q, :int(counts[q])] = torch.randint(0, ndocs, (int(counts[q]),), generator=gen)
+    Q = nrm(gen, nq, Lq, h)
+    cc = counts.to(torch.int32).cuda()
+    full = r.score_candidates(Q, cand.cuda()).cpu()
+    counted = r.score_candidates(Q, cand.cuda(), cand_count=cc).cpu()
+    general = g.score_candidates(Q, cand.cuda(), cand_count=cc).cpu()
+    assert torch.equal(full, counted) and torch.equal(full, general)
+    live = cand >= 0
+    assert torch.isinf(full[~live]).all() and torch.isfinite(full[live]).all()
+    # counted top-k over the same rows
+    k = 10
+    p1, s1 = r.topk(full.cuda(), cand.cuda(), k, cc)
+    exp_s = torch.sort(full, dim=1, descending=True, stable=True).values[:, :k]
+    assert torch.equal(s1.cpu(), exp_s)
+
+
+def test_multiview_goldens_from_the_imported_reference(ca, golden):
+    """`mv768_fp16.npz` was written by tests/golden/make_golden.py from the imported BaseModel.score on the reference's
+    default multi-view shape (Q 2 x 16 x 768, D 32 x 16 x 768, fp16-rounded values scored in fp32; dense.yaml:8,29-32),
+    `mv128_fp16.npz` on BASELINE configs[3]'s shape in the reference's storage dtype (Q 2 x 8 x 128, D 64 x 8 x 128): the
+    fused rerank on an fp16 index of those docs must reproduce the [q, d] matrix (|d| <= 1e-3), through the static grid,
+    counted rows and the operator seam."""
+    for name, L, h in (("mv768_fp16", 16, 768), ("mv128_fp16", 8, 128)):
+        gd = golden(name)
+        assert gd["D"].dtype == torch.float16                            # stored in the index's own dtype
+        Q, D, exp = gd["Q"], gd["D"].float(), gd["expected"]
+        nq, nd = Q.size(0), D.size(0)
+        assert tuple(D.shape[1:]) == (L, h) and Q.size(1) == L
+        idx = gd["D"].reshape(nd * L, h)
+        r = ca.ColbertRanker(parts=[idx], parts_doclens=[[L] * nd], dim=h, index_dtype=torch.float16)
+        assert r._iv.uniform_len == L
+        cand = torch.arange(nd).repeat(nq, 1)
+        got = r.score_candidates(Q, cand.cuda()).cpu()
+        np.testing.assert_allclose(got.numpy(), exp.numpy(), rtol=0, atol=ATOL16)
+        cc = torch.full((nq,), nd, dtype=torch.int32).cuda()
+        assert torch.equal(r.score_candidates(Q, cand.cuda(), cand_count=cc).cpu(), got)
+        assert torch.equal(without_promise(r).score_candidates(Q, cand.cuda()).cpu(), got)
+        # the operator seam on the same tensors (fp32 operands holding fp16 values, ones masks as colbert_ranker.py:108-112)
+        ones_q, ones_d = torch.ones(nq, L, dtype=torch.long), torch.ones(nd, L, dtype=torch.long)
+        dense = ca.score(Q.cuda(), D.cuda(), ones_q.cuda(), ones_d.cuda()).cpu()
+        np.testing.assert_allclose(dense.numpy(), exp.numpy(), rtol=0, atol=1e-4)
+        # rank_forward (the reference's call: Q [1, h, Lq], python list of pids): the oracle's order on the golden's scores
+        for qi in range(nq):
+            pids, scores = r.rank_forward(Q[qi:qi + 1].permute(0, 2, 1), list(range(nd)), depth=10)
+            order = torch.sort(exp[qi], descending=True, stable=True).indices[:10].tolist()
+            assert pids == order or np.allclose(scores, exp[qi][order].numpy(), atol=ATOL16)
+            np.testing.assert_allclose(scores, exp[qi][order].numpy(), rtol=0, atol=ATOL16)
+
+
+@pytest.mark.parametrize("name,L,lq,h,ndocs", [("mv128", 8, 8, 128, 1_000_000), ("mv768", 16, 16, 768, 200_000)])
+def test_multiview_full_batch_properties(ca, name, L, lq, h, ndocs):
+    """BASELINE-sized launches (256 queries x 1000 candidates) of the two multi-view shapes on an fp16 index, through
+    size-independent properties: permuting a query's candidate list permutes its scores (bitwise); a candidate's score does not
+    depend on its neighbours in the list nor on the batch (one query alone == the same row of the batch, bitwise); doubling
+    an fp16 query doubles the score (exact in floating point); a sample agrees with fp32 torch on the stored values."""
+    dev = torch.device("cuda", 0)
+    gen = torch.Generator(device=dev).manual_seed(9)
+    idx = torch.empty(ndocs * L, h, dtype=torch.float16, device=dev)
+    step = 1 << 19
+    for a in range(0, idx.size(0), step):
+        b = min(a + step, idx.size(0))
+        idx[a:b] = F.normalize(torch.randn(b - a, h, generator=gen, device=dev), dim=-1).half()
+    r = ca.ColbertRanker.from_device_tensor(idx, [L] * ndocs)
+    assert r._iv.uniform_len == L
+    nq, ncand = 256, 1000
+    Q = F.normalize(torch.randn(nq, lq, h, generator=gen, device=dev), dim=-1)
+    cand = torch.stack([torch.randperm(ndocs, generator=gen, device=dev)[:ncand] for _ in range(nq)])
+    s = r.score_candidates(Q, cand)
+    assert torch.isfinite(s).all()
+    perm = torch.randperm(ncand, generator=gen, device=dev)
+    assert torch.equal(r.score_candidates(Q, cand[:, perm]), s[:, perm])
+    assert torch.equal(r.score_candidates(Q[17:18], cand[17:18, :333]), s[17:18, :333])
+    Qh = Q.half()                                         # a 16-bit query has no low piece: doubling it is exact end to end
+    assert torch.equal(r.score_candidates(2.0 * Qh, cand), 2.0 * r.score_candidates(Qh, cand))
+    qs, cs = Q[:3], cand[:3, :50]
+    rows = (cs.unsqueeze(-1) * L + torch.arange(L, device=dev)).view(3, -1)
+    D = idx[rows].float().view(3, 50, L, h)
+    exp = torch.einsum("qmh,qdnh->qdmn", qs, D).max(-1).values.sum(-1)
+    np.testing.assert_allclose(s[:3, :50].cpu().numpy(), exp.cpu().numpy(), rtol=0, atol=ATOL16)
+    # top-100 of the full batch == stable sort of the score matrix
+    top_p, top_s = r.topk(s, cand, 100)
+    exp_s, exp_i = torch.sort(s, dim=1, descending=True, stable=True)
+    assert torch.equal(top_s, exp_s[:, :100]) and torch.equal(top_p, cand.gather(1, exp_i[:, :100]))

@@ -149,6 +149,27 @@ def test_percentile_and_keep_nonzero():
     assert q.tolist() == [[0, 1, 2], [6, 7, 8]] and m.tolist() == [1, 1]
 
 
+@pytest.mark.parametrize("name,view,dim", [("mv768_fp16", 16, 768), ("mv128_fp16", 8, 128)])
+def test_multiview_fp16_goldens(golden, name, view, dim):
+    """The reference's multi-view deployment shapes in its storage dtype (dense.yaml:8,29-32; colbert_ranker.py:62), written
+    by tests/golden/make_golden_multiview.py through the imported get_representation + score: the torch and plain-C
+    restatements of `score`, and the restated ranker on an fp16 index of those docs (one length bucket = the view count, no
+    0-floor), reproduce the expected matrix."""
+    from oracle import c_oracle
+    g = golden(name)
+    assert g["D"].dtype == torch.float16 and tuple(g["D"].shape[1:]) == (view, dim)
+    Q, D, exp = g["Q"], g["D"].float(), g["expected"]
+    nq, nd = Q.size(0), D.size(0)
+    qm, dm = torch.ones(nq, view, dtype=torch.long), torch.ones(nd, view, dtype=torch.long)
+    torch.testing.assert_close(ref_score(Q, D, qm, dm), exp, rtol=0, atol=1e-5)
+    np.testing.assert_allclose(c_oracle.score_dense(Q.numpy(), D.numpy(), qm.numpy(), dm.numpy()), exp.numpy(), rtol=0, atol=2e-5)
+    r = RefRanker([g["D"].reshape(nd * view, dim)], [[view] * nd], dim=dim)
+    assert r.strides == [view]
+    for qi in range(nq):
+        sc = r.all_scores(Q[qi:qi + 1].permute(0, 2, 1).contiguous(), list(range(nd)))
+        torch.testing.assert_close(torch.as_tensor(sc, dtype=torch.float32), exp[qi], rtol=0, atol=1e-5)
+
+
 # ---- the plain-C restatement (oracle/maxsim_oracle.c), independent of torch/BLAS ---------------------------------
 def test_c_oracle_against_goldens_and_torch_oracle(golden):
     from oracle import c_oracle
