@@ -23,10 +23,10 @@ NEG_INF = float("-inf")
 
 
 def shard_range(n_docs_total, rank, world):
-    """Contiguous pid range [lo, hi) of a rank (same structure as the reference's per-part files, loaders.py:7-19)."""
-    per = (n_docs_total + world - 1) // world
-    lo = min(rank * per, n_docs_total)
-    return lo, min(lo + per, n_docs_total)
+    """Contiguous pid range [lo, hi) of a rank (same structure as the reference's per-part files, loaders.py:7-19): the
+    balanced cut -- shard sizes differ by at most one doc, and no shard is empty as long as the index has at least
+    ``world`` docs (with ceil(n / world)-sized shards the last ranks of a small index got nothing: 12 docs on 8 ranks)."""
+    return (rank * n_docs_total) // world, ((rank + 1) * n_docs_total) // world
 
 
 def localize(cand_global, lo, hi):
@@ -289,6 +289,9 @@ class ShardedRanker:
                                       "use the single-GPU ColbertRanker")
         dev = self.local.device
         n_total = self.n_docs_total
+        if n_total is None:
+            raise ValueError("rank_forward needs n_docs_total (the docs of the WHOLE index: the pid range check and the "
+                             "negative-pid wrap of colbert_ranker.py:88)")
         pids_t = (torch.tensor(pids, dtype=torch.int64) if type(pids) is list else pids.to(torch.int64)).view(1, -1)
         lo, hi = (int(x) for x in torch.aminmax(pids_t))
         if hi >= n_total or lo < -n_total:                                     # `self.doclens[pids]`, :88
@@ -331,9 +334,11 @@ def load_shard(index_path, rank=None, world=None, device="cuda", index_dtype=tor
     parts_doclens = index_io.load_doclens(index_path, flatten=False)          # :22
     doclens = [int(x) for y in parts_doclens for x in y]
     n_total = len(doclens)
+    # every rank knows n_total and world: an index with fewer docs than ranks is refused by ALL ranks here, before any
+    # collective (a rank that raised alone would leave the others waiting in the constructor's all_reduce)
+    if n_total < world:
+        raise ValueError(f"the index has {n_total} docs, fewer than the {world} ranks: at least one doc per shard is needed")
     lo, hi = shard_range(n_total, rank, world)
-    if hi <= lo:
-        raise ValueError(f"shard {rank} of {world} is empty: the index has only {n_total} docs")
     strides = reference_strides(torch.tensor(doclens, dtype=torch.int64))    # of the WHOLE index
     tok_lo = sum(doclens[:lo])
     # walk the parts: docs [d0, d1) and token rows [t0, t1) of each; keep the overlap with [lo, hi)

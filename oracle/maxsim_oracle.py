@@ -85,7 +85,7 @@ class RefRanker:
     ``score_fn`` is the object's ``model.score`` (default: ``ref_score``).
     """
 
-    def __init__(self, parts, parts_doclens, dim=None, score_fn=ref_score, index_dtype=torch.float16):
+    def __init__(self, parts, parts_doclens, dim=None, score_fn=ref_score, index_dtype=torch.float16, strides=None):
         self.maxsim_dtype = torch.float32                              # :20
         self.parts_doclens = parts_doclens
         self.doclens = [x for y in parts_doclens for x in y]          # flatten, utils.py:133
@@ -100,16 +100,21 @@ class RefRanker:
             offset = endpos
         self.tensor = tensor
         self.score_fn = score_fn
-        self.init_ranker()
+        self.init_ranker(strides)
 
-    def init_ranker(self):                                             # :31-43
+    def init_ranker(self, strides=None):                               # :31-43
+        # strides (not in the reference): a DOC SHARD of a bigger index is bucketed by the strides of the whole index
+        # (tests of the doc-sharded path); None = the reference's own rule below
         self.doclens_pfxsum = [0] + list(accumulate(self.doclens))
         self.doclens = torch.tensor(self.doclens)
         self.doclens_pfxsum = torch.tensor(self.doclens_pfxsum)
         self.dim = self.tensor.size(-1)
-        self.strides = [torch_percentile(self.doclens, p) for p in [25, 50, 75]]
-        self.strides.append(self.doclens.max().item())
-        self.strides = sorted(list(set(self.strides)))
+        if strides is None:
+            self.strides = [torch_percentile(self.doclens, p) for p in [25, 50, 75]]
+            self.strides.append(self.doclens.max().item())
+            self.strides = sorted(list(set(self.strides)))
+        else:
+            self.strides = sorted(int(x) for x in strides)
         self.views = self._create_views(self.tensor)
 
     def _create_views(self, tensor):                                   # :45-51

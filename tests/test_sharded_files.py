@@ -49,9 +49,7 @@ def oracle_fns(sh, strides):
     """Scorer / ids->pids for a CPU shard: the oracle over the shard's OWN rows bucketed by the strides the shipped
     loader derived (``sh.local.strides``), and the reference's emb2pid + set() (colbert_ranker.py:163-174, :212-229)."""
     loc = sh.local
-    ref = RefRanker([loc.tensor], [loc.doclens.tolist()], dim=loc.dim)
-    ref.strides = list(strides)
-    ref.views = ref._create_views(ref.tensor)
+    ref = RefRanker([loc.tensor], [loc.doclens.tolist()], dim=loc.dim, strides=strides)   # (a 1-doc shard has no percentiles)
     emb2pid = torch.repeat_interleave(torch.arange(loc.n_docs), loc.doclens)
 
     def scorer(Q, cand_local, q_mask=None, q_len=None):
@@ -105,11 +103,13 @@ def _worker(rank, world, port, tmp_r, tmp_m, ret):
         checks = {}
         # --- ragged_rerank_64: rank_forward from files
         z = np.load(os.path.join(GOLD, "ragged_rerank_64.npz"))
-        sh = load_cpu_shard(tmp_r, None if rank else 0, None if rank else world)   # rank 1 takes rank/world from the group
-        checks["range"] = (sh.lo, sh.hi) == ((0, 32) if rank == 0 else (32, 64))
+        from colbert_amd.sharded import shard_range
+        sh = load_cpu_shard(tmp_r, None if rank else 0, None if rank else world)   # ranks > 0 take rank/world from the group
+        checks["range"] = (sh.lo, sh.hi) == shard_range(64, rank, world)
         checks["global_strides"] = sh.local.strides == z["strides"].tolist()
         checks["pad_len"] = sh.local.d_pad_len.tolist() == z["pad_len"][sh.lo:sh.hi].tolist()
-        checks["tok_lo"] = sh.tok_lo == (0 if rank == 0 else int(z["doclens0"].sum()))
+        dl_all = z["doclens0"].tolist() + z["doclens1"].tolist()
+        checks["tok_lo"] = sh.tok_lo == sum(dl_all[:sh.lo]) and sh.tok_hi == sum(dl_all[:sh.hi])
         checks["n_docs_total"] = sh.n_docs_total == 64
         Q = torch.from_numpy(z["Q"])
         pids = z["pids"].tolist()
@@ -139,12 +139,37 @@ def _worker(rank, world, port, tmp_r, tmp_m, ret):
             checks["empty_asserts"] = False
         except AssertionError:
             checks["empty_asserts"] = True
+        # a list that lives on ONE shard only (the last rank's docs): every other rank's share of it is empty -- its local
+        # top-k is all (-1, -inf) padding, which must cross all_gather_topk + merge_gathered without winning a slot; and
+        # depth (10) larger than what any rank holds of a 4-pid list spread over the shards
+        score_of = dict(zip(pids, z["expected_scores"].tolist()))
+        last_lo, last_hi = shard_range(64, world - 1, world)
+        own = [p for p in pids if last_lo <= p < last_hi]
+        got_p, got_s = sh.rank_forward(Q, own, depth=10)
+        want = sorted(own, key=lambda p: -score_of[p])[:10]
+        checks["one_shard_list"] = (len(got_p) == min(10, len(own)) and np.allclose(got_s, [score_of[p] for p in want], rtol=0, atol=1e-5)
+                                    and all(abs(score_of[p] - sc) <= 1e-5 for p, sc in zip(got_p, got_s)))
+        few = [pids[0], pids[21], pids[42], pids[63]]
+        got_p, got_s = sh.rank_forward(Q, few, depth=10)
+        want = sorted(few, key=lambda p: -score_of[p])
+        checks["k_above_live_count"] = got_p == want and np.allclose(got_s, [score_of[p] for p in want], rtol=0, atol=1e-5)
+        # rerank_batch on a 2-query batch whose second row is all padding on every rank but one
+        from colbert_amd.sharded import all_gather_topk, merge_gathered
+        Qt = Q.permute(0, 2, 1).contiguous()
+        cand2 = torch.full((2, 64), -1, dtype=torch.int64)
+        cand2[0] = torch.tensor(pids)
+        cand2[1, :len(own)] = torch.tensor(own)
+        top_p, top_s = sh.rerank_batch(torch.cat([Qt, Qt]), cand2, depth=12)
+        n1 = min(12, len(own))
+        checks["batch_with_padding_rows"] = (top_p[0, :10].tolist() == z["top10_pids"].tolist()
+                                             and sorted(top_p[1, :n1].tolist()) == sorted(sorted(own, key=lambda p: -score_of[p])[:n1])
+                                             and bool((top_p[1, n1:] == -1).all()) and bool(torch.isinf(top_s[1, n1:]).all()))
 
         # --- masked_query_rerank: the batched driver from files, global token rows in
         m = np.load(os.path.join(GOLD, "masked_query_rerank.npz"))
         shm = load_cpu_shard(tmp_m, rank, world)
         dl = m["doclens0"].tolist() + m["doclens1"].tolist()
-        checks["m_range"] = (shm.lo, shm.hi) == ((0, 6) if rank == 0 else (6, 12))   # part0 has 5 docs: part1 is sliced
+        checks["m_range"] = (shm.lo, shm.hi) == shard_range(12, rank, world)          # part0 has 5 docs: parts are sliced
         Qm, keep = torch.from_numpy(m["Q"]), torch.from_numpy(m["q_word_mask"])
         ids = cover_ids(dl, Qm.size(1), 4, Qm.size(0), seed=11)
         from colbert_amd import retrieve_batch
@@ -190,15 +215,55 @@ def _worker(rank, world, port, tmp_r, tmp_m, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_sharded_from_files_world2(tmp_path):
+def _spawn(world, tmp_path):
     tmp_r, tmp_m = str(tmp_path / "ragged"), str(tmp_path / "masked")
     write_index(tmp_r, "ragged_rerank_64.npz")
     write_index(tmp_m, "masked_query_rerank.npz")
-    world, port = 2, _free_port()
+    port = _free_port()
     ret = mp.Manager().dict()
     mp.spawn(_worker, args=(world, port, tmp_r, tmp_m, ret), nprocs=world, join=True)
-    assert dict(ret) == {0: [], 1: []}          # per rank: the names of the failed checks
+    assert dict(ret) == {r: [] for r in range(world)}          # per rank: the names of the failed checks
+
+
+@pytest.mark.timeout(300)
+def test_sharded_from_files_world2(tmp_path):
+    _spawn(2, tmp_path)
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("world", [3, 8])
+def test_sharded_from_files_uneven_worlds(tmp_path, world):
+    """The same checks THROUGH THE COLLECTIVES at world 3 and 8 (gloo): shards of unequal size (64 docs: 21 / 21 / 22; 12
+    docs on 8 ranks: one or two each), ranks whose share of a list is empty, depth above a rank's live count, negative pids,
+    the batched driver on global token rows -- every rank must return the goldens' results."""
+    _spawn(world, tmp_path)
+
+
+def _tiny_worker(rank, world, port, tmp, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import datetime
+    dist.init_process_group("gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=60))
+    try:
+        try:
+            load_cpu_shard(tmp, rank, world)
+            ret[rank] = "no error"
+        except ValueError as e:
+            ret[rank] = str(e)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_index_smaller_than_world_is_refused_by_every_rank(tmp_path):
+    """A 1-doc index on 2 ranks: BOTH ranks raise before any collective (a rank raising alone would leave the other in the
+    constructor's all_reduce until the process-group timeout)."""
+    from colbert_amd.index_io import save_index
+    g = torch.Generator().manual_seed(0)
+    save_index(str(tmp_path), [torch.nn.functional.normalize(torch.randn(5, 128, generator=g), dim=-1).half()], [[5]])
+    ret = mp.Manager().dict()
+    mp.spawn(_tiny_worker, args=(2, _free_port(), str(tmp_path), ret), nprocs=2, join=True)
+    assert all("fewer than the 2 ranks" in ret[r] for r in range(2)), dict(ret)
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 5, 8])
@@ -227,8 +292,10 @@ def test_load_shard_slices_parts(tmp_path, world):
 def test_load_shard_errors(tmp_path):
     from colbert_amd.sharded import load_shard
     write_index(str(tmp_path), "masked_query_rerank.npz")          # 12 docs
-    with pytest.raises(ValueError, match="empty"):
-        load_shard(str(tmp_path), 7, 8, device="cpu", score_fn=lambda *a: None, topk_fn=cpu_topk)   # ceil(12/8)=2: ranks 6, 7 get nothing
+    with pytest.raises(ValueError, match="fewer than the 13 ranks"):
+        load_shard(str(tmp_path), 7, 13, device="cpu", score_fn=lambda *a: None, topk_fn=cpu_topk)
+    sh = load_shard(str(tmp_path), 7, 8, device="cpu", score_fn=lambda *a: None, topk_fn=cpu_topk)  # 12 docs on 8 ranks: nobody is empty
+    assert (sh.lo, sh.hi) == (10, 12)
     with pytest.raises(ValueError, match="rank and world"):
         load_shard(str(tmp_path), device="cpu")                     # no process group to take them from
 

@@ -197,7 +197,11 @@ def test_shard_candidates_cpu_counts_and_single_process_checks():
 
 def test_shard_range_and_localize():
     from colbert_amd.sharded import localize, merge_gathered, shard_range
-    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 9), (9, 10)]
+    assert [shard_range(10, r, 4) for r in range(4)] == [(0, 2), (2, 5), (5, 7), (7, 10)]      # balanced: sizes differ by <= 1
+    assert [shard_range(12, r, 8) for r in range(8)] == [(0, 1), (1, 3), (3, 4), (4, 6), (6, 7), (7, 9), (9, 10), (10, 12)]   # none empty
+    for n, w in ((1, 1), (7, 3), (64, 5), (1000, 8), (8, 8)):
+        rs = [shard_range(n, r, w) for r in range(w)]
+        assert rs[0][0] == 0 and rs[-1][1] == n and all(a[1] == b[0] for a, b in zip(rs, rs[1:])) and all(hi > lo for lo, hi in rs)
     assert [shard_range(8, r, 8) for r in range(8)] == [(i, i + 1) for i in range(8)]
     c = torch.tensor([[0, 5, 9, 3], [4, 4, 2, 8]])
     loc, inr = localize(c, 3, 6)
