@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: rocprofv3 kernel-trace + PMC passes of bench.py for the round's profiled workloads.
 # usage: tools/run_profiles.sh <round-tag, e.g. r03> "<names>"      names from: c2_f32 c2_fp16 c2_f32fast c2_f32bf16x3 c5_bf16
-#        c4_f32 ragged_f32 ragged_f32bf16x3 ragged_fp16 dep768_fp16 c2_shard8_f32 (one rank's share of an 8-way doc-sharded job) single_query
+#        c4_f32 ragged_f32 ragged_f32bf16x3 ragged_fp16 dep768_fp16 mv128_fp16 mv768_fp16 c2_shard8_f32 (one rank's share of an 8-way doc-sharded job) single_query
 set -u
 TAG=${1:-r04}
 NAMES=${2:-"c2_f32 c2_fp16 c2_f32bf16x3 c5_bf16 c4_f32 ragged_f32 dep768_fp16 c2_shard8_f32 single_query"}
@@ -27,6 +27,8 @@ for n in $NAMES; do
     ragged_fp16) prof ragged_fp16 --workload ragged --index-dtype fp16 ;;
     ragged_f32bf16x3) prof ragged_f32bf16x3 --workload ragged --fp32-mode bf16x3 ;;
     dep768_fp16) prof dep768_fp16 --workload dep768 ;;
+    mv128_fp16) prof mv128_fp16 --workload mv128 ;;
+    mv768_fp16) prof mv768_fp16 --workload mv768 ;;
     c2_shard8_f32) prof c2_shard8_f32 --workload c2 --as-rank 3 --of 8 ;;
     single_query)  # the reference's online call: one rank_forward per query (tools/bench_small.py loops it)
       NDOCS=1000000 NQS=1,16 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_single_query_trace -- python3 $R/tools/bench_small.py > $R/gpurun_out/${TAG}_single_query_trace.log 2>&1 &&
