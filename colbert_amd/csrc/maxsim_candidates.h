@@ -180,67 +180,86 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
   uint32_t* scan = table + TS;                 // [1024]
   uint32_t* flags = scan + nt;                 // [0] = overflow
   const int q = blockIdx.x, tid = threadIdx.x;
+#ifdef MAXSIM_STAMP_UNIQUE   // timing builds only: 100 MHz stamps of workgroup 0's phases behind out_count[gridDim.x] (a buffer the probe makes longer)
+  uint64_t* const stamp_out = (uint64_t*)(out_count + ((gridDim.x + 1) & ~1u));
+#define UQ_STAMP(i) do { if (q == 0 && tid == 0) stamp_out[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define UQ_STAMP(i)
+#endif
+  UQ_STAMP(0);
   for (int i = tid; i < TS; i += nt) table[i] = kNoKey;
   if (tid == 0) flags[0] = 0;
   __syncthreads();
+  UQ_STAMP(1);
 
-  // ---- look up and insert, G ids per thread at a time (their loads are independent: one latency per round, not per id)
-  constexpr int G = 8;
+  // ---- look up and insert.  A thread's ids (i = tid, tid + 1024, ...: 16 of a 16384-id query) are loaded ALL AT ONCE, then
+  // their row-block entries all at once: the workgroup's chain is one id-load latency + one table-load latency (two rounds
+  // of 8 paid both twice: stamped at 13.1 us of a 28 us one-query launch).  The rest -- the rare search inside a block with
+  // several docs, the LDS inserts -- runs in halves of G = 8 to stay inside the 128 registers a 1024-thread workgroup gets.
+  constexpr int G = 8, R = 16;
   const int64_t last = n_docs - 1;
-  for (int i0 = tid; i0 < n; i0 += G * nt) {
-    int64_t e[G];
-    uint32_t lo[G], hi[G];
+  for (int i0 = tid; i0 < n; i0 += R * nt) {
+    int64_t ea[R];
+    uint64_t enta[R];
 #pragma unroll
-    for (int g = 0; g < G; ++g) e[g] = candidate_row(emb_ids, q, n, i0 + g * nt, id_base, tok_keep, ids_per_token, n_tokens);
+    for (int g = 0; g < R; ++g) ea[g] = candidate_row(emb_ids, q, n, i0 + g * nt, id_base, tok_keep, ids_per_token, n_tokens);
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      lo[g] = 0;
-      hi[g] = e[g] >= 0 ? (uint32_t)last : 0u;
-      if (row_blocks != nullptr && e[g] >= 0) {
-        const int64_t b = e[g] >> kRowBlockShift;
-        const uint64_t ent = row_blocks[b];
-        const uint32_t d0 = (uint32_t)ent, bnd = (uint32_t)(ent >> 32) & 127u;
-        lo[g] = d0;
-        if ((ent >> 39) & 1) hi[g] = (uint32_t)row_blocks[b + 1];                     // rare: search between the two entries
-        else lo[g] = hi[g] = d0 + ((bnd != 0 && ((uint32_t)e[g] & 63u) >= bnd) ? 1u : 0u);
-      }
-    }
-    // the doc of row e: the LAST pid in [lo, hi] whose first row is <= e (tok_offsets[lo] <= e holds on entry)
-    bool open = false;
+    for (int g = 0; g < R; ++g) enta[g] = (row_blocks != nullptr && ea[g] >= 0) ? row_blocks[ea[g] >> kRowBlockShift] : 0ull;
 #pragma unroll
-    for (int g = 0; g < G; ++g) open |= lo[g] < hi[g];
-    while (__any(open)) {
-      uint32_t mid[G];
-      int64_t off[G];
+    for (int half = 0; half < R / G; ++half) {
+      int64_t e[G];
+      uint32_t lo[G], hi[G];
 #pragma unroll
       for (int g = 0; g < G; ++g) {
-        mid[g] = lo[g] + ((hi[g] - lo[g] + 1) >> 1);
-        off[g] = lo[g] < hi[g] ? tok_offsets[mid[g]] : 0;
-      }
-      open = false;
-#pragma unroll
-      for (int g = 0; g < G; ++g) {
-        if (lo[g] < hi[g]) {
-          if (off[g] <= e[g]) lo[g] = mid[g]; else hi[g] = mid[g] - 1;
+        e[g] = ea[half * G + g];
+        lo[g] = 0;
+        hi[g] = e[g] >= 0 ? (uint32_t)last : 0u;
+        if (row_blocks != nullptr && e[g] >= 0) {
+          const uint64_t ent = enta[half * G + g];
+          const uint32_t d0 = (uint32_t)ent, bnd = (uint32_t)(ent >> 32) & 127u;
+          lo[g] = d0;
+          if ((ent >> 39) & 1) hi[g] = (uint32_t)row_blocks[(e[g] >> kRowBlockShift) + 1];   // rare: search between the two entries
+          else lo[g] = hi[g] = d0 + ((bnd != 0 && ((uint32_t)e[g] & 63u) >= bnd) ? 1u : 0u);
         }
-        open |= lo[g] < hi[g];
       }
-    }
+      // the doc of row e: the LAST pid in [lo, hi] whose first row is <= e (tok_offsets[lo] <= e holds on entry)
+      bool open = false;
 #pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (e[g] < 0) continue;
-      const uint32_t pid = lo[g];
-      uint32_t h = (pid * 2654435761u) >> (32 - log_ts);
-      int probes = 0;
-      for (;;) {
-        const uint32_t prev = atomicCAS(&table[h], kNoKey, pid);
-        if (prev == kNoKey || prev == pid) break;
-        h = (h + 1) & (TS - 1);
-        if (++probes > 64) { flags[0] = 1; break; }   // the set is (nearly) full: this query takes the full sort
+      for (int g = 0; g < G; ++g) open |= lo[g] < hi[g];
+      while (__any(open)) {
+        uint32_t mid[G];
+        int64_t off[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          mid[g] = lo[g] + ((hi[g] - lo[g] + 1) >> 1);
+          off[g] = lo[g] < hi[g] ? tok_offsets[mid[g]] : 0;
+        }
+        open = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+          if (lo[g] < hi[g]) {
+            if (off[g] <= e[g]) lo[g] = mid[g]; else hi[g] = mid[g] - 1;
+          }
+          open |= lo[g] < hi[g];
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        if (e[g] < 0) continue;
+        const uint32_t pid = lo[g];
+        uint32_t h = (pid * 2654435761u) >> (32 - log_ts);
+        int probes = 0;
+        for (;;) {
+          const uint32_t prev = atomicCAS(&table[h], kNoKey, pid);
+          if (prev == kNoKey || prev == pid) break;
+          h = (h + 1) & (TS - 1);
+          if (++probes > 64) { flags[0] = 1; break; }   // the set is (nearly) full: this query takes the full sort
+        }
       }
     }
   }
   __syncthreads();
+  UQ_STAMP(2);
   if (flags[0] != 0) {
     __syncthreads();
     unique_by_full_sort((uint32_t*)lds, scan, q, n, P, emb_ids, id_base, tok_keep, ids_per_token, tok_offsets, n_docs, n_tokens,
@@ -248,13 +267,15 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
     return;
   }
 
-  // ---- compact the set in place: thread t owns table slots [t * spt, (t + 1) * spt), spt = 4 / 8 / 16
+  // ---- compact the set in place: thread t owns table slots t, t + 1024, ... (spt = 4 / 8 / 16 of them).  (Slots
+  // [t * spt, (t + 1) * spt) read with a lane stride of spt words: 32 lanes on one LDS bank at spt = 16 -- stamped at 5.2 us
+  // of a 28 us one-query launch; the order of the compacted keys does not matter, they are sorted next.)
   const int spt = TS / nt;
   uint32_t v[16];
   uint32_t cnt = 0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    v[j] = j < spt ? table[tid * spt + j] : kNoKey;
+    v[j] = j < spt ? table[j * nt + tid] : kNoKey;
     cnt += v[j] != kNoKey ? 1u : 0u;
   }
   uint32_t incl = cnt;                          // inclusive scan inside the wave, then over the 16 waves' totals
@@ -280,6 +301,7 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
   while (P2 < (int)total) P2 <<= 1;
   for (int i = (int)total + tid; i < P2; i += nt) keys[i] = kNoKey;
   __syncthreads();
+  UQ_STAMP(3);
   // ---- sort the distinct pids (they are distinct: nothing to drop afterwards)
   if (total > 1) {
     if (P2 == 1024) bitonic_sort_regs<1, uint32_t, false>(keys, P2, tid);
@@ -288,8 +310,11 @@ __global__ void __launch_bounds__(1024) k_unique_pids(const int64_t* __restrict_
     else if (P2 == 8192) bitonic_sort_regs<8, uint32_t, false>(keys, P2, tid);
     else bitonic_sort_regs<16, uint32_t, false>(keys, P2, tid);
   }
+  UQ_STAMP(4);
   for (int i = tid; i < n; i += nt) out_pids[(int64_t)q * n + i] = i < (int)total ? (int64_t)keys[i] : (int64_t)-1;
   if (tid == 0) out_count[q] = (int32_t)total;
+  UQ_STAMP(5);
 }
+
 
 }  // namespace maxsim

@@ -173,3 +173,88 @@ def test_multiview_full_batch_properties(ca, name, L, lq, h, ndocs):
     top_p, top_s = r.topk(s, cand, 100)
     exp_s, exp_i = torch.sort(s, dim=1, descending=True, stable=True)
     assert torch.equal(top_s, exp_s[:, :100]) and torch.equal(top_p, cand.gather(1, exp_i[:, :100]))
+
+
+# ------------------------------------------------------------------------------------------------------
+# ids -> distinct pids in every regime of the row-block table (written for round 5's block-level de-duplication experiment,
+# docs/experiments.md "ids -> distinct pids: block set"; the regimes stay as coverage of k_unique_pids)
+# ------------------------------------------------------------------------------------------------------
+def _emb2pid(doclens):
+    return torch.repeat_interleave(torch.arange(len(doclens)), torch.tensor(doclens))     # colbert_ranker.py:163-174
+
+
+def _expect(e, e2p, keep=None, base=0):
+    """sorted(set(emb2pid[ids])) per query (colbert_ranker.py:212-229, :234) over the live ids."""
+    nq = e.size(0)
+    flat = e.reshape(nq, -1)
+    out = []
+    for q in range(nq):
+        ids = flat[q]
+        if keep is not None:
+            ids = e[q][keep[q].bool()].flatten()
+        ids = ids - base
+        ids = ids[(ids >= 0) & (ids < e2p.numel())]
+        out.append(sorted(set(e2p[ids].tolist())))
+    return out
+
+
+def _check(cand, cnt, exp):
+    cand, cnt = cand.cpu(), cnt.cpu()
+    for q, want in enumerate(exp):
+        assert int(cnt[q]) == len(want), (q, int(cnt[q]), len(want))
+        assert cand[q, :len(want)].tolist() == want, q
+        assert bool((cand[q, len(want):] == -1).all()), q
+
+
+@pytest.mark.parametrize("regime", ["long_docs", "two_doc_boundaries", "short_docs_with_empties", "one_token_docs", "huge_docs"])
+@pytest.mark.parametrize("n", [16384, 5000, 300])
+def test_ids_to_pids_row_block_regimes(ca, regime, n):
+    """Bit-exact against sorted(set(emb2pid[ids])) in every block regime of the row-block table: blocks inside one doc, blocks
+    with one doc boundary (ids on both sides of it, on one side only, exactly at it), blocks with many docs and empty docs in
+    between (a search between two table entries), one-token docs (64 docs per block); ids clustered on a few hot docs (many
+    ids per block and per doc), ids spread over up to n distinct blocks, ids on both sides of doc boundaries, FAISS's -1
+    padding, rows outside the index, a shard's id_base and the keep-mask."""
+    g = torch.Generator().manual_seed(len(regime) * 1000 + n)
+    if regime == "long_docs":
+        doclens = torch.randint(100, 400, (6000,), generator=g).tolist()
+    elif regime == "two_doc_boundaries":
+        doclens = torch.randint(60, 70, (20000,), generator=g).tolist()                  # nearly every block holds one boundary
+    elif regime == "short_docs_with_empties":
+        doclens = torch.randint(0, 12, (150000,), generator=g).tolist()
+        doclens[1000:1400] = [0] * 400                                                   # a long run of empty docs
+    elif regime == "one_token_docs":
+        doclens = [1] * 700000
+    else:
+        doclens = [5000, 1, 70000, 0, 0, 3, 64, 64, 128, 1000000]                        # blocks of one doc for thousands of blocks
+    doclens[0] = max(doclens[0], 1)
+    emb = torch.zeros(sum(doclens), 16, dtype=torch.float16)                             # (the rows' values do not matter here)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=16, index_dtype=torch.float16)
+    e2p = _emb2pid(doclens)
+    ntok = e2p.numel()
+    offs = torch.tensor([0] + doclens).cumsum(0)
+    nq = 5
+    e = torch.empty(nq, n, dtype=torch.int64)
+    e[0] = torch.randint(0, ntok, (n,), generator=g)                                     # spread: up to n distinct blocks
+    hot = torch.randint(0, len(doclens), (40,), generator=g)                             # clustered on 40 docs
+    hot = hot[torch.tensor(doclens)[hot] > 0]
+    pick = hot[torch.randint(0, hot.numel(), (n,), generator=g)]
+    e[1] = offs[pick] + (torch.rand(n, generator=g) * torch.tensor(doclens)[pick]).long()
+    starts = offs[:-1][torch.tensor(doclens) > 0]                                        # first / last rows of docs: the boundaries
+    sel = starts[torch.randint(0, starts.numel(), (n,), generator=g)]
+    e[2] = sel - (torch.arange(n) % 2)                                                   # a doc's first row, or the row before it
+    e[2].clamp_(0, ntok - 1)
+    e[3] = torch.arange(n) * max(1, ntok // n) % ntok                                    # an arithmetic walk: distinct blocks when ntok is large
+    e[4] = e[0]
+    e[4, ::3] = -1                                                                       # FAISS "no neighbour"
+    e[4, 1::7] = ntok + 17                                                               # outside the index
+    cand, cnt = r.embedding_ids_to_pids(e.cuda(), trim=False)
+    _check(cand, cnt, _expect(e, e2p))
+    # a shard's view: ids shifted by id_base, foreign rows dropped; a keep-mask over 4 "query tokens"
+    if n % 4 == 0:
+        keep = torch.tensor([[1, 0, 1, 1]] * nq)
+        keep[3] = 0
+        base = 777
+        eb = (e + base).view(nq, 4, n // 4)
+        cand, cnt = r.embedding_ids_to_pids(eb.cuda(), trim=False, keep=keep, id_base=base)
+        _check(cand, cnt, _expect(eb, e2p, keep, base))
+        assert int(cnt[3]) == 0
