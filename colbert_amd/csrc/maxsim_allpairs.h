@@ -88,6 +88,11 @@ __device__ __forceinline__ void lds_barrier() {  // this wave's LDS stores are d
 #ifndef AP_DMA_BSPLIT
 #define AP_DMA_BSPLIT 0
 #endif
+// (timing experiment: -DAP_MFMA16=1 issues every 32x32x16 MFMA as two 16x16x32 on quarters of its accumulator: same flops,
+//  operand reads and pipe cycles, WRONG results -- what the matrix shape alone does to the clock the chip holds)
+#ifndef AP_MFMA16
+#define AP_MFMA16 0
+#endif
 
 template <int DT, int R, int QB, bool AM>
 __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
@@ -218,6 +223,19 @@ __global__ void __launch_bounds__(512) k_maxsim_allpairs(const AllPairsArgs a) {
   do {                                                                                                                \
     if (AP_ABLATE_MFMA) break;                                                                                        \
     const int q_ = (i) / R, b_ = (i) % R;                                                                             \
+    if (AP_MFMA16) { /* timing experiment, WRONG results: the same flops, operands and cycles as two 16x16x32 */      \
+      f32x4 c0_, c1_;                                                                                                 \
+      _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { c0_[t_] = acc[b_][q_][8 * (set) + t_]; c1_[t_] = acc[b_][q_][8 * (set) + 4 + t_]; } \
+      if constexpr (DT == MAXSIM_F16) {                                                                               \
+        c0_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[set][b_]), __builtin_bit_cast(f16x8, fb[set][q_]), c0_, 0, 0, 0); \
+        c1_ = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, fa[set][b_]), __builtin_bit_cast(f16x8, fb[set][q_]), c1_, 0, 0, 0); \
+      } else {                                                                                                        \
+        c0_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[set][b_]), __builtin_bit_cast(bf16x8, fb[set][q_]), c0_, 0, 0, 0); \
+        c1_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fa[set][b_]), __builtin_bit_cast(bf16x8, fb[set][q_]), c1_, 0, 0, 0); \
+      }                                                                                                               \
+      _Pragma("unroll") for (int t_ = 0; t_ < 4; ++t_) { acc[b_][q_][8 * (set) + t_] = c0_[t_]; acc[b_][q_][8 * (set) + 4 + t_] = c1_[t_]; } \
+      break;                                                                                                          \
+    }                                                                                                                 \
     const f32x16 c_ = (c0) ? (f32x16)(0.0f) : acc[b_][q_];                                                            \
     if constexpr (DT == MAXSIM_F16)                                                                                   \
       acc[b_][q_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, fa[set][b_]), __builtin_bit_cast(f16x8, fb[set][q_]), c_, 0, 0, 0); \

@@ -33,6 +33,8 @@ template <int DT, bool AM>
 int launch_dt(const AllPairsArgs& a, hipStream_t st) {
   if (a.Ld <= 128) return launch_r<DT, 1, 4, AM>(a, st);
   if (a.Ld <= 256) return launch_r<DT, 2, 4, AM>(a, st);
+  // (the same tile on v_mfma_f32_16x16x32 -- a higher held clock in the timing experiment -DAP_MFMA16=1, 2.48 -> 2.31 ms -- was
+  //  built, bit-identical, and no faster: tools/attic/allpairs16/README.md)
   return launch_r<DT, 3, 3, AM>(a, st);
 }
 
