@@ -284,9 +284,6 @@ class ShardedRanker:
         assert Q.size(0) in [1, len(pids)]                                    # :77
         if Q.size(0) != 1:
             raise NotImplementedError("rank_forward with one query per candidate is not exercised by the reference")
-        if output_D_embedding:
-            raise NotImplementedError("output_D_embedding on a doc-sharded index: the top docs' rows live on other ranks; "
-                                      "use the single-GPU ColbertRanker")
         dev = self.local.device
         n_total = self.n_docs_total
         if n_total is None:
@@ -301,6 +298,8 @@ class ShardedRanker:
         Qt = Q.permute(0, 2, 1)                                               # :111 -> [1, Lq, h]
         top_p, top_s = self.rerank_batch(Qt, cand, depth=min(int(depth), cand.size(1)))
         out_p, out_s = top_p[0].tolist(), top_s[0].tolist()
+        if output_D_embedding:                                                # :131-136
+            D, mask = self._output_D(top_p[0], cand[0])
         if lo < 0:
             # :129 returns the caller's own values (`pids[order]`): hand every wrapped pid back as it was passed in
             # (a doc listed twice, as p and p - N, has one score; which of the two spellings comes first is a tie)
@@ -308,7 +307,57 @@ class ShardedRanker:
             for orig, c in zip(pids_t[0].tolist(), cand[0].tolist()):
                 back.setdefault(c, []).append(orig)
             out_p = [back[c].pop(0) for c in out_p]
+        if output_D_embedding:
+            return out_p, D, mask
         return out_p, out_s
+
+    def _reduce(self, t, op):
+        """all_reduce of a small tensor over the shard group (staged through the host when CUDA tensors meet gloo: the
+        one-GPU rehearsal)."""
+        if self._world() == 1:
+            return t
+        stage = t.is_cuda and dist.get_backend(self.group) == "gloo"
+        x = t.cpu() if stage else t
+        dist.all_reduce(x, op=op, group=self.group)
+        return x.to(t.device) if stage else x
+
+    def _output_D(self, top_pids, all_cand):
+        """colbert_ranker.py:131-136 on the doc-sharded index: D [k, S, h] fp32 and mask [k, S] of the top docs as the
+        reference's strided view hands them over (:49, :105) -- slot t of a doc is token row offset + t of the CONCATENATED
+        index whatever doc it belongs to: slots past a doc's end hold the next docs' tokens, which for the last docs of a shard
+        live on the NEXT rank, and zeros past the end of the whole index (the reference's +512-row tail, :62).  Three small
+        all_reduces: the candidates' length bucket (the reference's ``torch.cat`` works only when ALL candidates fall in one
+        bucket, :132: same restriction, same error, on every rank), the top docs' (first global row, length) from their owners,
+        and the rows themselves, every rank contributing the rows it holds."""
+        loc = self.local
+        dev = top_pids.device
+        lo, hi = self.lo, self.hi
+        mine = (all_cand >= lo) & (all_cand < hi)
+        pad = loc.d_pad_len.to(dev)[(all_cand[mine] - lo)].to(torch.int64)
+        big = 1 << 40
+        mm = torch.tensor([-(int(pad.min().item()) if pad.numel() else big), int(pad.max().item()) if pad.numel() else -1],
+                          dtype=torch.int64, device=dev)
+        mm = self._reduce(mm, dist.ReduceOp.MAX)
+        S_min, S = -int(mm[0].item()), int(mm[1].item())
+        if S_min != S:
+            raise RuntimeError("Sizes of tensors must match except in dimension 0 (candidates span several length buckets)")
+        if self.tok_lo is None or self.tok_hi is None:
+            raise ValueError("output_D_embedding needs tok_lo (the global token row of this shard's first token)")
+        k = top_pids.numel()
+        own = (top_pids >= lo) & (top_pids < hi)
+        info = torch.zeros(k, 2, dtype=torch.int64, device=dev)               # (first global row, doclen), from the owner
+        lp = top_pids[own] - lo
+        info[own, 0] = self.tok_lo + loc.d_offsets.to(dev)[lp]
+        info[own, 1] = loc.d_doclens.to(dev)[lp].to(torch.int64)
+        info = self._reduce(info, dist.ReduceOp.SUM)
+        ar = torch.arange(S, device=dev)
+        rows = info[:, 0:1] + ar.unsqueeze(0)                                 # [k, S] global token rows
+        held = (rows >= self.tok_lo) & (rows < self.tok_hi)
+        D = torch.zeros(k, S, loc.tensor.size(-1), dtype=torch.float32, device=dev)
+        D[held] = loc.tensor.to(dev)[(rows[held] - self.tok_lo)].to(torch.float32)     # :107
+        D = self._reduce(D, dist.ReduceOp.SUM)                                # every row is held by exactly one rank (or none: zeros)
+        mask = ar.unsqueeze(0) + 1 <= info[:, 1:2]                            # :108-109
+        return D, mask
 
 
 def load_shard(index_path, rank=None, world=None, device="cuda", index_dtype=torch.float16, group=None, fp32_mode="exact",

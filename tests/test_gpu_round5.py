@@ -258,3 +258,25 @@ def test_ids_to_pids_row_block_regimes(ca, regime, n):
         cand, cnt = r.embedding_ids_to_pids(eb.cuda(), trim=False, keep=keep, id_base=base)
         _check(cand, cnt, _expect(eb, e2p, keep, base))
         assert int(cnt[3]) == 0
+
+
+def test_sharded_output_D_embedding_on_gpu(ca, tmp_path):
+    """ShardedRanker.rank_forward(output_D_embedding=True) (colbert_ranker.py:131-136) on the HIP path: a one-shard "sharded"
+    index returns what the single-GPU ColbertRanker returns (pids, D [k, S, h] fp32 incl. the aliased slots past a doc's end
+    and the zero tail, mask); the multi-rank exchange of the rows is covered on CPU ranks (tests/test_sharded_files.py)."""
+    import os
+    from colbert_amd.index_io import save_index
+    from colbert_amd.sharded import load_shard
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ragged_rerank_64.npz"))
+    save_index(str(tmp_path), [torch.from_numpy(z["part0"]), torch.from_numpy(z["part1"])], [z["doclens0"].tolist(), z["doclens1"].tolist()])
+    whole = ca.ColbertRanker(index_path=str(tmp_path), device="cuda:0")
+    sh = load_shard(str(tmp_path), 0, 1, device="cuda:0")
+    Q = torch.from_numpy(z["Q"]).cuda()
+    pad = z["pad_len"].tolist()
+    for bucket in sorted(set(pad)):
+        one = [p for p in z["pids"].tolist() if pad[p] == bucket]
+        gp, gD, gm = sh.rank_forward(Q, one, depth=6, output_D_embedding=True)
+        ep, eD, em = whole.rank_forward(Q, one, depth=6, output_D_embedding=True)
+        assert gp == ep and torch.equal(gD, eD) and torch.equal(gm, em)
+    with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
+        sh.rank_forward(Q, z["pids"].tolist(), depth=6, output_D_embedding=True)

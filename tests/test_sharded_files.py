@@ -165,6 +165,25 @@ def _worker(rank, world, port, tmp_r, tmp_m, ret):
                                              and sorted(top_p[1, :n1].tolist()) == sorted(sorted(own, key=lambda p: -score_of[p])[:n1])
                                              and bool((top_p[1, n1:] == -1).all()) and bool(torch.isinf(top_s[1, n1:]).all()))
 
+        # output_D_embedding (colbert_ranker.py:131-136) across shards: the top docs' padded rows as the reference's strided
+        # view hands them over -- incl. slots past a doc's end that belong to the next doc / the next SHARD / the zero tail --
+        # against the restated ranker over the whole index; candidates of ONE length bucket (the reference's torch.cat, :132)
+        whole_ref = RefRanker([torch.from_numpy(z["part0"]), torch.from_numpy(z["part1"])],
+                              [z["doclens0"].tolist(), z["doclens1"].tolist()], dim=128)
+        pad_all = z["pad_len"].tolist()
+        for bucket in sorted(set(pad_all)):
+            one = [p for p in pids if pad_all[p] == bucket]                # (pids holds all 64 docs, the index's last one too: its
+                                                                           #  padding slots are the zero tail behind the index)
+            got_p, got_D, got_m = sh.rank_forward(Q, one, depth=7, output_D_embedding=True)
+            exp_p, exp_D, exp_m = whole_ref.rank_forward(Q, one, depth=7, output_D_embedding=True)
+            checks[f"output_D_{bucket}"] = (got_p == exp_p and torch.equal(got_D, exp_D.float()) and torch.equal(got_m, exp_m)
+                                            and got_D.dtype == torch.float32 and tuple(got_D.shape) == (min(7, len(one)), bucket, 128))
+        try:
+            sh.rank_forward(Q, pids, depth=5, output_D_embedding=True)     # all 64 docs: several buckets
+            checks["output_D_mixed_buckets_raise"] = False
+        except RuntimeError as e:
+            checks["output_D_mixed_buckets_raise"] = "Sizes of tensors must match" in str(e)
+
         # --- masked_query_rerank: the batched driver from files, global token rows in
         m = np.load(os.path.join(GOLD, "masked_query_rerank.npz"))
         shm = load_cpu_shard(tmp_m, rank, world)
