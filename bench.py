@@ -17,19 +17,28 @@ the batch is 256*N queries, every query has 1000 candidates drawn uniformly over
 per shard) and the same global lists are handed to every rank.  A step is the shipped sharded path:
 ShardedRanker.local_topk (maxsim_shard_candidates -> counted rerank from a device-built work list -> local top-100 with
 global pids) -> exchange_async (ONE RCCL all_gather + per-query merge, on a side stream, overlapping the next batch's
-rerank).  value = queries of all ranks / max-over-ranks time.  A second, labelled measurement ("stratified") runs the same
-path on lists with exactly 1000/N candidates per shard.
+rerank).  value = queries of all ranks / max-over-ranks time.  Two more, labelled measurements of the same path: "stratified"
+(lists with exactly 1000/N candidates per shard) and "per_shard_1000" (SURVEY 8d's other weak-scaling variant: lists of
+1000 x N pids, 1000 on every shard).  Candidates are drawn WITHOUT replacement within a list.
+`sharded_self_check_ok` says whether the from-files self-check (load_shard + rank_forward + retrieve_batch over the job's own
+process group == the unsharded HIP ranker) held on every rank.
 
 The default N = 1 run also reports, in the same JSON line and each driver-timed in this process:
   sharded_share   one rank's share of an N = 2 / 4 / 8 step on this GPU (256*N queries, ~1000/N live candidates per row):
                   what every rank of that job does before the exchange -- the expected weak-scaling curve's compute side
   other_workloads BASELINE configs[3], [4], the reference's fp16 storage dtype, ragged doclens, the reference's default
-                  deployment shape (dim 768 fp16 ragged) and the opt-in bf16x3 contraction of the fp32 index
+                  deployment shape (dim 768 fp16 ragged), its multi-view deployments on the fp16 index (mv128: 8 x 8 tokens
+                  dim 128; mv768: 16 x 16 tokens dim 768) and the opt-in bf16x3 contraction of the fp32 index
   single_query    the reference's online call (one rank_forward), training_form (the operator's second caller),
   cpu_baseline    the oracle on the host cores (never the product path), roofline.read_ceiling (measured on this box).
 and measures roofline.traffic / mfma_busy_frac itself: three `rocprofv3 --pmc` child runs come first, before this process
 touches the GPU (live_pmc: FETCH_SIZE over the headline and every other_workloads entry, WRITE_SIZE and the MFMA-busy
-counters on the headline; --no-pmc skips them and replays profiles/).
+counters on the headline -- the same pass gives roofline.effective_clock_GHz; --no-pmc skips them and replays profiles/).
+roofline.power is a best-effort sysfs sample of board power / cap / shader clock over the headline's steps.
+
+stdout carries ONE compact JSON line (the contract's fields + one numeric row per extra measurement, roofline last); the
+full record of the run -- every entry with its shape, method and sources -- is written to gpurun_out/bench_details.json
+(`details_file`).
 """
 import argparse
 import gc
@@ -563,6 +572,13 @@ def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32
         b2b = e0.elapsed_time(e1) / 20
         out["kernel_ms_back_to_back"] = round(b2b, 4)
         out["frac_back_to_back"] = round(alg / (b2b * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        # ... and THAT is the launch duration the entry reports (kernel_ms / achieved / frac): it is the one rocprofv3's
+        # kernel-trace average of the same kernel agrees with (profiles/r05_mv128_fp16_*: 0.0881 ms against 0.0879 here, 0.0974
+        # through the event pair); the event-pair figure stays beside it
+        out["kernel_ms_event_pair"], out["frac_event_pair"] = out["kernel_ms"], out["frac"]
+        out["kernel_ms"], out["frac"] = out["kernel_ms_back_to_back"], out["frac_back_to_back"]
+        out["achieved"] = round(alg / (b2b * 1e-3) / 1e9, 1)
+        out["mfma_tflops"] = round(2.0 * lq * h * cand_tokens / (b2b * 1e-3) / 1e12, 1)
         # ... and what a bigger batch per launch reads (a launch this short pays its ramp and its one-round tail in full):
         # 8 x the queries, same docs per query
         nq8 = 8 * NQ
@@ -1180,9 +1196,11 @@ def retrieve_step_probe(ranker, Q, dev, faiss_depth=512, hot=1500):
                                         "frac": round(rerank_bytes / b / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": rerank_bytes},
             "ids_to_pids_roofline": {"bound": "hbm", "achieved": round(ids_bytes / a / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                      "frac": round(ids_bytes / a / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": ids_bytes,
-                                     "note": "one 1024-thread workgroup per query: hash-set dedupe in LDS + a 2048-key register sort; "
-                                             "latency- and LDS-bound, not a streaming kernel (round 3: 0.21 ms)"},
-            "profile": "profiles/r04_retrieve_step_kernel_stats.csv, profiles/r04_retrieve_step_pmc.json (tools/bench_retrieve_step.py)"}
+                                     "note": "one 1024-thread workgroup per query: 16 384 divergent 8-byte table lookups through one CU's "
+                                             "vector-memory path, hash-set dedupe in LDS, a 2048-key register sort; bound by that "
+                                             "lookup rate and the workgroup's serial chain, not by bytes (stamped phases: "
+                                             "docs/experiments.md round 5)"},
+            "profile": "profiles/r05_retrieve_step_kernel_stats.csv, profiles/r05_retrieve_step_pmc.json (tools/bench_retrieve_step.py)"}
 
 
 def single_query_probe(ranker, Q, cands, H, LQ, esize):
@@ -1190,7 +1208,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     list in, python lists out, host-synchronous -- latency, not throughput.  `gpu_span_ms` is the time between two HIP
     events recorded on the launch stream right before and after the call (both kernels + the gap between them);
     `host_ms` = end-to-end minus that span (the events themselves add a few us to the span: the kernel's own duration is
-    in profiles/r04_single_query_*)."""
+    in profiles/r05_single_query_*)."""
     Q1 = Q[:1].float().permute(0, 2, 1)     # [1, h, Lq]: the permuted VIEW of a [1, Lq, h] tensor, as faiss_indexers.py:232-233 hands it over
     out = {"call": "rank_forward(Q[1,h,Lq], 1000 pids, depth=100) -> python lists"}
     lat, span = [], []
@@ -1220,7 +1238,7 @@ def single_query_probe(ranker, Q, cands, H, LQ, esize):
     out.update({"median_ms": round(med, 4), "min_ms": round(lat[0] * 1e3, 4), "gpu_span_ms": round(gspan, 4),
                 "host_ms": round(max(med - gspan, 0.0), 4), "queries_per_s_sequential": round(1e3 / med, 1),
                 "algorithmic_GBps_over_gpu_span": round((ntok * H * esize + LQ * H * 4) / (gspan * 1e-3) / 1e9, 1),
-                "kernel_profile": "profiles/r04_single_query_summary.json"})
+                "kernel_profile": "profiles/r05_single_query_summary.json"})
     # 16 queries per launch (a small server batch): the rerank kernel alone, 20 launches back to back between two events
     ks = []
     for rep in range(5):
@@ -1317,10 +1335,10 @@ def training_form_probe(dev):
                         "frac_of_hbm_peak": round(bwd_total / bms / 1e6 / HBM_PEAK_GBS, 4),
                         "note": "the gathered rows are served by L2 / Infinity Cache (tables of 13 MB and 321 MB), not streamed from "
                                 "HBM: reference_rate = the guide's measured row-gather rate from a 38 MB table (MI355X_MICROARCH.md 'Indexed "
-                                "rows': 8.6 TB/s; 7.4-7.9 from 151 MB); per kernel (profiles/r04_train_*): dQ 7.6 TB/s, dD 9.8 TB/s "
+                                "rows': 8.6 TB/s; 7.4-7.9 from 151 MB); per kernel (profiles/r05_train_*): dQ 7.6 TB/s, dD 9.8 TB/s "
                                 "(partly L2), index pass 40 MB in 0.05 ms"},
-           "kernels": "profiles/r04_train_kernel_stats.csv: k_maxsim_bwd_dq_v8 0.954 ms (7.27 GB of D rows: 7.6 TB/s), k_maxsim_bwd_dd_rows "
-                      "0.811 ms (7.27 GB of Q rows + 0.64 GB written: 9.8 TB/s), k_maxsim_bwd_index 0.049 ms; PMC: profiles/r04_train_pmc.json"}
+           "kernels": "profiles/r05_train_kernel_stats.csv: k_maxsim_bwd_dq_v8 0.953 ms (7.27 GB of D rows: 7.6 TB/s), k_maxsim_bwd_dd_rows "
+                      "0.811 ms (7.27 GB of Q rows + 0.64 GB written: 9.8 TB/s), k_maxsim_bwd_index 0.049 ms; PMC: profiles/r05_train_pmc.json"}
     return {"op": "maxsim_score_dense_fwd (scores + arg-max) / maxsim_score_dense_bwd (dQ, dD), Q 272x32x768 x D 544x384x768, bf16, prefix d_mask",
             "kernel": "k_maxsim_allpairs" if _lib.lib.maxsim_score_dense_kernel(nq, nd, lq, ld, h, bf, mf) == 1 else "k_maxsim_stream_bigh",
             "forward_ms": round(ms, 4), "backward_ms": round(bms, 4), "forward_backward_ms": round(ms + bms, 4),
@@ -1328,7 +1346,7 @@ def training_form_probe(dev):
             "frac": round(flop / ms / 1e9 / 2500.0, 4), "vendor_gemm": vendor,
             "frac_of_vendor_square_gemm": round(flop / ms / 1e9 / vendor["square_8192_bf16_tflops"], 4), "how": "20 launches back to back between two HIP events, forward and backward separately",
             "backward": bwd,
-            "profile": "profiles/r04_train_kernel_stats.csv, profiles/r04_train_pmc.json (forward with arg-max 2.50 ms, without 2.33 ms; "
+            "profile": "profiles/r05_train_kernel_stats.csv, profiles/r05_train_pmc.json (forward with arg-max 2.49 ms, without 2.33 ms; "
                        "r02_allpairs_* hold the forward's SQ counter passes)"}
 
 

@@ -42,10 +42,16 @@
 extern "C" {
 #endif
 
-#define MAXSIM_VERSION 122 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
+#define MAXSIM_VERSION 123 /* 0.1.1: maxsim_index_view, maxsim_rerank_ex (q_mask, doc table), maxsim_rank_forward,
                               maxsim_shard_candidates, maxsim_build_doc_table; 111: maxsim_score_dense_kernel;
                               120: counted candidate rows (maxsim_rerank_counted, maxsim_topk_counted);
-                              121: maxsim_index_view.uniform_len, read-ceiling probes, maxsim_host_alloc_coherent */
+                              121: maxsim_index_view.uniform_len, read-ceiling probes, maxsim_host_alloc_coherent;
+                              122: maxsim_embedding_ids_to_pids_ex (tok_keep, id_base, row-block table:
+                                   maxsim_row_blocks_bytes / maxsim_build_row_blocks), maxsim_index_view_bytes,
+                                   maxsim_index_view.struct_size in place of `reserved` (checked by maxsim_rerank_ex,
+                                   maxsim_rerank_counted and maxsim_rank_forward: 0 or the caller's sizeof, else MAXSIM_EINVAL);
+                              123: no new symbol -- uniform_len = 4 / 8 / 16 now also selects a fixed-length kernel on an
+                                   fp16 / bf16 index (the reference's multi-view storage); same results, bit for bit */
 
 /* element types of Q / D / index */
 #define MAXSIM_F32 0

@@ -30,7 +30,7 @@ def test_header_symbols_exported(lib):
 
 
 def test_version_and_strerror(lib):
-    assert lib.lib.maxsim_version() == 122
+    assert lib.lib.maxsim_version() == 123
     assert lib.strerror(0) == "ok"
     for code in (-1, -2, -3, -4):
         assert lib.strerror(code) not in ("ok", "unknown error")
