@@ -579,8 +579,15 @@ constexpr int SPLIT_MAX_DOCS = 8;  // docs per team of waves in a SPLITK launch 
 // LIST (counted candidate rows, maxsim_worklist.h): the grid is fixed and every WAVE walks the device-built list of wave
 //   items (query, first slot, docs): item = global wave id, + waves in the grid, ...; the waves of a workgroup share
 //   nothing (each holds its own query registers), so they may be on different queries.
-template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false, bool LIST = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
+// BAL (static-grid rerank of a RAGGED index): the workgroup's docs are dealt to its waves by TOKENS, not by count.  A wave's
+//   stream is ~12 docs of 120 +- 40 tokens: with equal doc counts the waves of a workgroup differ by +-10 % in length and the
+//   workgroup keeps its LDS until its longest wave is done.  Every wave loads the descriptors of ALL the workgroup's docs (one
+//   per lane: dpw <= 64), scans the lengths, and takes the contiguous run of docs whose midpoints fall into its quarter of the
+//   workgroup's tokens.  Per-doc arithmetic is untouched: scores are bit-identical; uniform indexes keep the plain cut, and so
+//   does the fp32 index (power-limited: no gain measured, tu_stream.hip).
+template <int MODE, int DT, int WAVES, int NT, int ABLATE = 0, int QT = 32, bool SPLITK = false, bool LIST = false, bool BAL = false>  // ABLATE (diagnostic): 1 = no MFMA, 2 = no DMA
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
+  static_assert(!BAL || (MODE == MODE_RERANK && !SPLITK && !LIST), "token-balanced cut: static-grid rerank only");
   static_assert(MODE == MODE_RERANK || DT == MAXSIM_F32, "dense (masked) mode is exact fp32 only");
   static_assert(!LIST || (MODE == MODE_RERANK && !SPLITK), "work-list form: rerank, unsplit");
   static_assert(!SPLITK || (MODE == MODE_RERANK && QT == QT_2X16 && WAVES == 4), "split form: two 16-column blocks only");
@@ -600,7 +607,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   const int split = SPLITK ? p.split : 1;
   const int team = SPLITK ? wave / split : wave, part = SPLITK ? wave - team * split : 0;
   // one wave item: candidates [c_begin, c_begin + ndoc) of query qi
-  auto wave_item = [&](const int qi, const int c_begin, const int ndoc) __attribute__((always_inline)) {
+  auto wave_item = [&](const int qi, const int c_begin, const int ndoc, const DocLanes* pre = nullptr) __attribute__((always_inline)) {
 #ifdef MAXSIM_STAMP  // timing builds only (tools/probe_timeline.py): 100 MHz stamps of this wave's phases -> p.d_mask
   uint64_t stamp[6];
   stamp[0] = __builtin_amdgcn_s_memrealtime();
@@ -608,7 +615,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 #else
 #define MAXSIM_STAMP_AT(i)
 #endif
-  DocLanes dl = load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
+  DocLanes dl = pre ? *pre : load_doc_lanes<MODE>(p, qi, c_begin, ndoc, threadIdx.x & 63);
   if constexpr (SPLITK) {
     const int per = (((dl.len + 31) >> 5) + split - 1) / split * 32;  // rows per slice
     const int start = min(dl.len, part * per);
@@ -1178,9 +1185,36 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   } else {
     int qi, chunk;
     wg_to_work((int)blockIdx.x, p.nq, p.nchunk, qi, chunk);
+    if constexpr (BAL) {
+      const int c0 = chunk * p.dpw, nwg = max(0, min(p.dpw, p.ncand - c0));     // the workgroup's docs: one per lane (dpw <= 64)
+      const DocLanes all = load_doc_lanes<MODE>(p, qi, c0, nwg, lane);
+      int incl = all.len;                                                         // inclusive scan of the lengths over the lanes
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        incl += lane >= d ? t : 0;
+      }
+      const int64_t T = __builtin_amdgcn_readlane(incl, 63);
+      const int64_t mid2 = 2 * (int64_t)(incl - all.len) + all.len;               // twice the doc's midpoint in the workgroup's stream
+      // docs in front of wave w's share: those whose midpoint lies below w T / WAVES (midpoints are non-decreasing over the
+      // lanes, so the ballot is a prefix mask); padding slots and empty docs (length 0) go with their neighbours
+      auto cut = [&](int w) {
+        if (w <= 0) return 0;
+        if (w >= WAVES) return nwg;
+        return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < nwg && mid2 * WAVES < 2 * (int64_t)w * T));
+      };
+      const int s0 = cut(wave), s1 = cut(wave + 1);
+      DocLanes mine;
+      mine.row0 = (uint32_t)__shfl((int)all.row0, (lane + s0) & 63);
+      mine.len = __shfl(all.len, (lane + s0) & 63);
+      mine.flags = __shfl(all.flags, (lane + s0) & 63);
+      if (lane >= s1 - s0) { mine.row0 = 0; mine.len = 0; mine.flags = 2; }
+      wave_item(qi, c0 + s0, s1 - s0, &mine);
+    } else {
     const int dpwv = SPLITK ? p.dpw / (WAVES / split) : p.dpw / WAVES;  // docs per wave / per team (<= 64; SPLITK: <= SPLIT_MAX_DOCS)
     const int c_begin = chunk * p.dpw + team * dpwv;
     wave_item(qi, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
+    }
   }
 }
 

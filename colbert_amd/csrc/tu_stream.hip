@@ -15,6 +15,20 @@ int launch_stream_v(Params& p, hipStream_t st) {
   p.dpw = dpwv * WAVES;
   p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
   const int ldsb = WAVES * NT * StreamTraits<DT>::TILE;
+  if constexpr (MODE == MODE_RERANK && ABLATE == 0 && (DT == MAXSIM_F16 || DT == MAXSIM_BF16)) {
+    // a ragged 16-bit index (no fixed-length promise), a workgroup's docs fitting one per lane: the token-balanced cut (BAL).
+    // Measured on ragged docs N(120, 40), 256 x 1000 (interleaved, tools/run_bal_ab.sh): fp16 index 0.777 -> 0.791 of the HBM
+    // peak (+1.0 .. +3.3 % in every one of six pairs), bf16 +0.5 .. +3.8 %; the fp32 index does not gain (exact: 0.629 vs 0.628,
+    // bf16x3 -1 %: power-limited, an idle wave only raises the others' clock) and keeps the equal-count cut.
+    // (diagnostic: MAXSIM_BAL=0 keeps the equal-count cut)
+    if (p.uniform_len == 0 && p.dpw <= 64 && dpwv >= 2 && MAXSIM_KNOB("MAXSIM_BAL", 1) != 0) {
+      auto kb = k_maxsim_stream<MODE, DT, WAVES, NT, ABLATE, QT, false, false, true>;
+      int rc = allow_lds(kb, ldsb);
+      if (rc) return rc;
+      hipLaunchKernelGGL(kb, dim3((unsigned)(p.nq * p.nchunk)), dim3(WAVES * 64), ldsb, st, KARGS_PASS(p));
+      return check_launch();
+    }
+  }
   auto kern = k_maxsim_stream<MODE, DT, WAVES, NT, ABLATE, QT>;
   int rc = allow_lds(kern, ldsb);
   if (rc) return rc;
