@@ -1,5 +1,7 @@
 // maxsim_launch_bigh.h -- launch heuristics of the LDS-query streaming kernel (included by the two tu_bigh_*.hip units).
 #pragma once
+#include <type_traits>
+
 #include "maxsim_launch.h"
 #include "maxsim_stream_bigh.h"
 
@@ -17,18 +19,26 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
   int dpwv = MAXSIM_KNOB("MAXSIM_DPW", 0);
   if (dpwv <= 0 || dpwv > 64) dpwv = pick_docs_per_wave(p, 4);
   const bool knob_dpw = MAXSIM_KNOB("MAXSIM_DPW", 0) > 0;
-  auto go = [&](auto kern, int waves, int nt) {
-    // (workgroups resident at once: one per CU above 80 KiB of LDS, else two)
-    const int dw = (MODE == MODE_RERANK && !knob_dpw) ? refine_docs_per_wave(p, dpwv, waves, qbytes + waves * nt * SUB > 80 * 1024 ? 256 : 512) : dpwv;
-    p.dpw = dw * waves;
-    p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
-    const int ldsb = qbytes + waves * nt * SUB;
+  auto launch = [&](auto kern, int waves, int ldsb) {
     int rc = allow_lds(kern, ldsb);
     if (rc) return rc;
     const int nqblk = (p.nq + QB - 1) / QB;
     hipLaunchKernelGGL(kern, dim3((unsigned)(nqblk * p.nchunk)), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
     return check_launch();
   };
+  // kern_bal: the same kernel with the token-balanced cut (ragged 16-bit index, a workgroup's docs one per lane), or nullptr
+  auto go2 = [&](auto kern, auto kern_bal, int waves, int nt) {
+    // (workgroups resident at once: one per CU above 80 KiB of LDS, else two)
+    const int dw = (MODE == MODE_RERANK && !knob_dpw) ? refine_docs_per_wave(p, dpwv, waves, qbytes + waves * nt * SUB > 80 * 1024 ? 256 : 512) : dpwv;
+    p.dpw = dw * waves;
+    p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
+    const int ldsb = qbytes + waves * nt * SUB;
+    if constexpr (!std::is_same<decltype(kern_bal), std::nullptr_t>::value) {
+      if (p.uniform_len == 0 && p.dpw <= 64 && dw >= 2 && MAXSIM_KNOB("MAXSIM_BAL", 1) != 0) return launch(kern_bal, waves, ldsb);
+    }
+    return launch(kern, waves, ldsb);
+  };
+  auto go = [&](auto kern, int waves, int nt) { return go2(kern, nullptr, waves, nt); };
   if constexpr (PART) {  // odd widths: one configuration (keeps the number of instantiations down)
     if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB, true>, 4, 1);
     return MAXSIM_ERANGE;
@@ -46,13 +56,20 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
         if (shape == 62 && avail >= 6 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 6, 2, AM, QB>, 6, 2);
       }
 #endif
-      if (avail >= 8 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
+      constexpr bool BALOK = MODE == MODE_RERANK && DT != MAXSIM_F32 && !AM;   // (ragged 16-bit indexes: the reference's deployment)
+      if (avail >= 8 * 2 * SUB) {
+        if constexpr (BALOK) return go2(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB, false, false, false, true>, 8, 2);
+        else return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
+      }
       // A two-piece query image (an fp32 query on a 16-bit index: the reference's deployment, dim 768 fp16 -> 96 KiB)
       // leaves 64 KiB for the rings: eight waves with one sub-tile each beat four waves with two -- the same bytes in
       // flight, but twice the matrix work per byte has twice the waves to hide behind (ragged dim-768 fp16 docs:
       // 13.45 -> 11.81 ms, 0.73 -> 0.83 of peak; with a one-piece image, e.g. C5, the two shapes measure the same)
       if constexpr (MODE == MODE_RERANK && NPQ == 2)
-        if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
+        if (avail >= 8 * 1 * SUB) {
+          if constexpr (BALOK) return go2(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB, false, false, false, true>, 8, 1);
+          else return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
+        }
       if (avail >= 4 * 2 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 2, AM, QB>, 4, 2);
     } else {  // several queries per workgroup: the matrix work per sub-tile is QB x longer, one sub-tile ahead suffices
       if (avail >= 8 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);

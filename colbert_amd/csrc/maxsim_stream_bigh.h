@@ -153,8 +153,12 @@ struct MultiReducer {
 // SPLITK (small launches -- the reference's online call is ONE query x ~1000 docs): a doc is streamed by p.split (2 or 4)
 //   waves of the workgroup, each a slice of whole 32-row tiles.  With one wave per doc the launch lasts as long as its
 //   LONGEST doc takes one wave (dim 768: 384 tokens = 72 sub-tiles of ~1.5 us), whatever the average.
-template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false, bool SPLITK = false>
+// BAL (static-grid rerank of a ragged index): the workgroup's docs are dealt to its waves by TOKENS instead of by count
+//   (k_maxsim_stream's BAL: descriptors of all the workgroup's docs one per lane, a scan of the lengths, contiguous runs by
+//   midpoint); bit-identical scores.
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false, bool SPLITK = false, bool BAL = false>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
+  static_assert(!BAL || (MODE == MODE_RERANK && QB == 1 && !LIST && !SPLITK), "token-balanced cut: static-grid rerank only");
   static_assert(!LIST || (MODE == MODE_RERANK && QB == 1 && !AM), "work-list form: rerank, one query per workgroup");
   static_assert(!SPLITK || (MODE == MODE_RERANK && QB == 1 && !AM && !LIST && !PART), "split form: static-grid rerank");
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
@@ -174,8 +178,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   // one workgroup item: the wave's candidates [c_begin, c_begin + ndoc) of the queries q0 .. q0 + QB - 1
   const int split = SPLITK ? p.split : 1;
   const int team = SPLITK ? wave / split : wave, part = SPLITK ? wave - team * split : 0;
-  auto wg_item = [&](const int q0, const int c_begin, const int ndoc) __attribute__((always_inline)) {
-  DocLanes dl = load_doc_lanes<MODE>(p, q0, c_begin, ndoc, lane);
+  auto wg_item = [&](const int q0, const int c_begin, const int ndoc, const DocLanes* pre = nullptr) __attribute__((always_inline)) {
+  DocLanes dl = pre ? *pre : load_doc_lanes<MODE>(p, q0, c_begin, ndoc, lane);
   if constexpr (SPLITK) {  // this wave's slice of every doc: whole 32-row tiles, cut as evenly as possible
     const int per = (((dl.len + 31) >> 5) + split - 1) / split * 32;
     const int start = min(dl.len, part * per);
@@ -441,10 +445,35 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
       qblk = blockIdx.x / p.nchunk;
       chunk = blockIdx.x - qblk * p.nchunk;
     }
+    if constexpr (BAL) {
+      const int c0 = chunk * p.dpw, nwg = max(0, min(p.dpw, p.ncand - c0));     // the workgroup's docs: one per lane (dpw <= 64)
+      const DocLanes all = load_doc_lanes<MODE>(p, qblk, c0, nwg, lane);
+      int incl = all.len;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int t = __shfl_up(incl, d);
+        incl += lane >= d ? t : 0;
+      }
+      const int64_t T = __builtin_amdgcn_readlane(incl, 63);
+      const int64_t mid2 = 2 * (int64_t)(incl - all.len) + all.len;
+      auto cut = [&](int w) {
+        if (w <= 0) return 0;
+        if (w >= WAVES) return nwg;
+        return (int)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < nwg && mid2 * WAVES < 2 * (int64_t)w * T));
+      };
+      const int s0 = cut(wave), s1 = cut(wave + 1);
+      DocLanes mine;
+      mine.row0 = (uint32_t)__shfl((int)all.row0, (lane + s0) & 63);
+      mine.len = __shfl(all.len, (lane + s0) & 63);
+      mine.flags = __shfl(all.flags, (lane + s0) & 63);
+      if (lane >= s1 - s0) { mine.row0 = 0; mine.len = 0; mine.flags = 2; }
+      wg_item(qblk, c0 + s0, s1 - s0, &mine);
+    } else {
     const int dpwv = SPLITK ? p.dpw / (WAVES / split) : p.dpw / WAVES;  // docs per wave / per team (SPLITK: <= SPLIT_MAX_DOCS)
     const int c_begin = chunk * p.dpw + team * dpwv;
     // (queries past nq - 1 are clamped and not written)
     wg_item(qblk * QB, c_begin, max(0, min(dpwv, p.ncand - c_begin)));
+    }
   }
 }
 

@@ -73,11 +73,15 @@ def test_hot_kernels_keep_their_registers_and_occupancy(tables):
 
 def test_headline_kernels_are_in_the_table(tables):
     want, _ = tables
-    for tu, name in (("tu_stream", "k_maxsim_stream<0, 0, 4, 1, 0, 48, false, false>"),        # C2 fp32 exact (headline)
-                     ("tu_stream", "k_maxsim_stream<0, 1, 4, 2, 0, 48, false, false>"),        # fp16 index
-                     ("tu_stream", "k_maxsim_stream<0, 2, 4, 2, 0, 48, false, false>"),        # bf16 index
+    for tu, name in (("tu_stream", "k_maxsim_stream<0, 0, 4, 1, 0, 48, false, false, false>"),        # C2 fp32 exact (headline)
+                     ("tu_stream", "k_maxsim_stream<0, 1, 4, 2, 0, 48, false, false, false>"),        # fp16 index
+                     ("tu_stream", "k_maxsim_stream<0, 2, 4, 2, 0, 48, false, false, false>"),        # bf16 index
+                     ("tu_stream", "k_maxsim_stream<0, 1, 4, 2, 0, 48, false, false, true>"),   # ragged fp16 index (token-balanced cut)
                      ("tu_stream", "k_maxsim_stream_uni<8, 1, 8, 0, false>"),                  # C4
-                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 2, 1, 4, 2, false, 1, false, false, false>"),   # C5
+                     ("tu_stream", "k_maxsim_stream_uni16<1, 8, 1, 8, 1, false>"),             # mv128
+                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 2, 1, 8, 2, false, 1, false, false, false, false>"),   # C5
+                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 1, 2, 8, 1, false, 1, false, false, false, true>"),    # dep768 (token-balanced cut)
+                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 1, 2, 8, 1, false, 1, false, false, false, false>"),   # mv768
                      ("tu_allpairs", "k_maxsim_allpairs<2, 3, 3, true>")):                     # training forward
         assert name in want[tu], name
         assert want[tu][name]["scratch"] == 0
@@ -86,7 +90,7 @@ def test_headline_kernels_are_in_the_table(tables):
 def test_the_guard_trips_on_a_moved_kernel(tables):
     """The comparison itself: a kernel that loses a wave per SIMD, gains a granule row, or spills must be reported."""
     want, got = tables
-    name = "k_maxsim_stream<0, 0, 4, 1, 0, 48, false, false>"
+    name = "k_maxsim_stream<0, 0, 4, 1, 0, 48, false, false, false>"
     for field, delta in (("vgpr", 64), ("scratch", 16), ("waves_per_simd", -1), ("lds_static", 1024)):
         moved = json.loads(json.dumps(got))
         moved["tu_stream"][name][field] += delta

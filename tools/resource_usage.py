@@ -23,10 +23,11 @@ FIELDS = {"VGPRs": "vgpr", "AGPRs": "agpr", "TotalSGPRs": "sgpr", "ScratchSize [
           "SGPRs Spill": "sgpr_spill"}
 # translation unit -> regular expressions of the kernels the test guards (demangled, without the argument list)
 GUARDED = {
-    "tu_stream": [r"k_maxsim_stream<0, [0-4], 4, [12], 0, (32|48), false, (false|true)>", r"k_maxsim_stream<0, 0, 4, 1, 0, 16, false, (false|true)>",
-                  r"k_maxsim_stream<1, 0, 4, 1, 0, 32, false, false>", r"k_maxsim_stream_uni<[48], [12], (4|8|16), 0, (false|true)>",
+    "tu_stream": [r"k_maxsim_stream<0, [0-4], 4, [12], 0, (32|48), false, (false|true), (false|true)>",
+                  r"k_maxsim_stream<0, 0, 4, 1, 0, 16, false, (false|true), false>",
+                  r"k_maxsim_stream<1, 0, 4, 1, 0, 32, false, false, false>", r"k_maxsim_stream_uni<[48], [12], (4|8|16), 0, (false|true)>",
                   r"k_maxsim_stream_uni16<.*>", r"k_maxsim_stream_f32h<.*>"],
-    "tu_bigh_rerank": [r"k_maxsim_stream_bigh<0, [012], [12], [48], [12], false, 1, false, false, false>", r"k_maxsim_bigh_uni<.*>"],
+    "tu_bigh_rerank": [r"k_maxsim_stream_bigh<0, [012], [12], [48], [12], false, 1, false, false, false, (false|true)>", r"k_maxsim_bigh_uni<.*>"],
     "tu_allpairs": [r"k_maxsim_allpairs<[12], [123], [34], (false|true)>"],
 }
 
