@@ -27,18 +27,19 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
     return check_launch();
   };
   // kern_bal: the same kernel with the token-balanced cut (ragged 16-bit index, a workgroup's docs one per lane), or nullptr
-  auto go2 = [&](auto kern, auto kern_bal, int waves, int nt) {
+  auto go3 = [&](auto kern, auto kern_bal, int waves, int nt, int qb) {   // qb: bytes of the staged query image(s)
     // (workgroups resident at once: one per CU above 80 KiB of LDS, else two)
-    const int dw = (MODE == MODE_RERANK && !knob_dpw) ? refine_docs_per_wave(p, dpwv, waves, qbytes + waves * nt * SUB > 80 * 1024 ? 256 : 512) : dpwv;
+    const int dw = (MODE == MODE_RERANK && !knob_dpw) ? refine_docs_per_wave(p, dpwv, waves, qb + waves * nt * SUB > 80 * 1024 ? 256 : 512) : dpwv;
     p.dpw = dw * waves;
     p.nchunk = (p.ncand + p.dpw - 1) / p.dpw;
-    const int ldsb = qbytes + waves * nt * SUB;
+    const int ldsb = qb + waves * nt * SUB;
     if constexpr (!std::is_same<decltype(kern_bal), std::nullptr_t>::value) {
       if (p.uniform_len == 0 && p.dpw <= 64 && dw >= 2 && MAXSIM_KNOB("MAXSIM_BAL", 1) != 0) return launch(kern_bal, waves, ldsb);
     }
     return launch(kern, waves, ldsb);
   };
-  auto go = [&](auto kern, int waves, int nt) { return go2(kern, nullptr, waves, nt); };
+  auto go2 = [&](auto kern, auto kern_bal, int waves, int nt) { return go3(kern, kern_bal, waves, nt, qbytes); };
+  auto go = [&](auto kern, int waves, int nt) { return go3(kern, nullptr, waves, nt, qbytes); };
   if constexpr (PART) {  // odd widths: one configuration (keeps the number of instantiations down)
     if (avail >= 4 * 1 * SUB) return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 4, 1, AM, QB, true>, 4, 1);
     return MAXSIM_ERANGE;
@@ -57,6 +58,23 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
       }
 #endif
       constexpr bool BALOK = MODE == MODE_RERANK && DT != MAXSIM_F32 && !AM;   // (ragged 16-bit indexes: the reference's deployment)
+      // docs of a few tokens (the multi-view configuration: 16 per doc): the launch is bound by how many waves stream, not by
+      // bytes in flight per wave -- mv768 with a one-piece image: 4 waves x 2 sub-tiles 0.684 of the HBM peak, 8 x 1 0.788,
+      // 12 x 1 0.796 (long docs: all shapes within 1 %)
+      const bool short_docs = p.n_docs > 0 && p.n_tokens <= 64 * p.n_docs;
+      if constexpr (BALOK) {
+        // at most 16 query tokens (q_view = 16, dense.yaml:31): the 16-row query image (HALFQ) -- half the LDS for the image,
+        // the rest goes to the rings; bit-identical scores (diagnostic: MAXSIM_HALFQ=0 keeps the 32-row image)
+        if (p.Lq <= 16 && MAXSIM_KNOB("MAXSIM_HALFQ", 1) != 0) {
+          const int qh = qbytes / 2, availh = 160 * 1024 - qh;
+          if (short_docs && availh >= 12 * 1 * SUB)
+            return go3(k_maxsim_stream_bigh<MODE, DT, NPQ, 12, 1, AM, QB, false, false, false, false, true>, nullptr, 12, 1, qh);
+          if (availh >= 8 * 2 * SUB)
+            return go3(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB, false, false, false, false, true>, nullptr, 8, 2, qh);
+          if (availh >= 8 * 1 * SUB)
+            return go3(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB, false, false, false, false, true>, nullptr, 8, 1, qh);
+        }
+      }
       if (avail >= 8 * 2 * SUB) {
         if constexpr (BALOK) return go2(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB, false, false, false, true>, 8, 2);
         else return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 2, AM, QB>, 8, 2);
@@ -65,8 +83,8 @@ int launch_stream_bigh_q(Params& p, hipStream_t st) {
       // leaves 64 KiB for the rings: eight waves with one sub-tile each beat four waves with two -- the same bytes in
       // flight, but twice the matrix work per byte has twice the waves to hide behind (ragged dim-768 fp16 docs:
       // 13.45 -> 11.81 ms, 0.73 -> 0.83 of peak; with a one-piece image, e.g. C5, the two shapes measure the same)
-      if constexpr (MODE == MODE_RERANK && NPQ == 2)
-        if (avail >= 8 * 1 * SUB) {
+      if constexpr (MODE == MODE_RERANK)
+        if ((NPQ == 2 || short_docs) && avail >= 8 * 1 * SUB) {
           if constexpr (BALOK) return go2(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB, false, false, false, true>, 8, 1);
           else return go(k_maxsim_stream_bigh<MODE, DT, NPQ, 8, 1, AM, QB>, 8, 1);
         }

@@ -26,7 +26,9 @@ namespace maxsim {
 // SPLIT (small launches, QB = 1): a doc is streamed by several waves, each a slice of its tokens; a finished slice PARKS its
 // per-query-token maxima in a register (parked[doc ordinal], lanes = query tokens) instead of finishing the score -- the
 // workgroup combines the slices after the stream (k_maxsim_stream_bigh).
-template <int QB, bool AM, bool SPLIT = false>
+// HALFQ (at most 16 query tokens, image of 16 rows): the 32 columns of the accumulators are the 16 tokens twice -- the upper
+// copy (lanes 16..31 of each half) is dropped before the sum over query tokens: it adds the +0.0 a zero query row would.
+template <int QB, bool AM, bool SPLIT = false, bool HALFQ = false>
 struct MultiReducer {
   float rmax[QB], myscore[QB];
   float parked[SPLIT ? SPLIT_MAX_DOCS : 1];
@@ -73,6 +75,7 @@ struct MultiReducer {
           v = fmaxf(a, b);
         }
         if (C.floor0) v = fmaxf(v, 0.0f);
+        if constexpr (HALFQ) v = (lane & 16) ? 0.0f : v;
         v += dpp_f32<0xB1>(v);
         v += dpp_f32<0x4E>(v);
         v += dpp_f32<0x141>(v);
@@ -156,9 +159,16 @@ struct MultiReducer {
 // BAL (static-grid rerank of a ragged index): the workgroup's docs are dealt to its waves by TOKENS instead of by count
 //   (k_maxsim_stream's BAL: descriptors of all the workgroup's docs one per lane, a scan of the lengths, contiguous runs by
 //   midpoint); bit-identical scores.
-template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false, bool SPLITK = false, bool BAL = false>
+// HALFQ (at most 16 query tokens -- the multi-view configuration's q_view = 16, dense.yaml:31 -- on a 16-bit index): the query
+//   image holds 16 rows instead of 32 (48 KiB instead of 96 at dim 768 with a two-piece image), the B-operand reads of query
+//   columns 16..31 alias columns 0..15 and the reducer drops them: the same arithmetic for the 16 real tokens (bit-identical
+//   scores), and the LDS it frees goes to the waves' rings -- at 16 tokens per doc the launch is bound by how many waves
+//   stream, not by bytes per wave (mv768: 8 waves x 1 sub-tile 0.755, 12 x 1 with the small image 0.79+).
+template <int MODE, int DT, int NPQ, int WAVES, int NT, bool AM, int QB, bool PART = false, bool LIST = false, bool SPLITK = false, bool BAL = false,
+          bool HALFQ = false>
 __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   static_assert(!BAL || (MODE == MODE_RERANK && QB == 1 && !LIST && !SPLITK), "token-balanced cut: static-grid rerank only");
+  static_assert(!HALFQ || (MODE == MODE_RERANK && QB == 1 && !AM && !PART && !SPLITK && DT != MAXSIM_F32), "16-row query image: 16-bit rerank");
   static_assert(!LIST || (MODE == MODE_RERANK && QB == 1 && !AM), "work-list form: rerank, one query per workgroup");
   static_assert(!SPLITK || (MODE == MODE_RERANK && QB == 1 && !AM && !LIST && !PART), "split form: static-grid rerank");
   static_assert(DT != MAXSIM_F32 || NPQ == 1, "fp32 index: the fp32 query is used as is");
@@ -186,7 +196,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
     dl.row0 += (uint32_t)start;
     dl.len = min(dl.len - start, per);  // may be 0: the slice then parks -inf maxima (neutral)
   }
-  const int qimg = NPQ * KB * SUB;                          // one query's image: [NPQ][KB][32 rows][BLKB]
+  constexpr int QROWS = HALFQ ? 16 : 32;                    // query tokens held in the image
+  constexpr int SUBQ = QROWS * BLKB;                        // bytes of one 128-dim block of it
+  const int qimg = NPQ * KB * SUBQ;                         // one query's image: [NPQ][KB][QROWS rows][BLKB]
   char* const qlds = lds;
   char* const wlds = lds + QB * qimg + wave * (NT * SUB);
   const int r = lane & 31, hh = lane >> 5;
@@ -226,13 +238,13 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
   {
     constexpr int CPB = BLKB / 16;       // 16-byte chunks per row block
     constexpr int EPC = 16 / ESZ;        // elements per chunk
-    const int nchunks = KB * 32 * CPB;
+    const int nchunks = KB * QROWS * CPB;
     for (int idx = threadIdx.x; idx < QB * nchunks; idx += WAVES * 64) {
       const int x = idx / nchunks;
       const int rem = idx - x * nchunks;
       const int c = rem % CPB;
-      const int n = (rem / CPB) & 31;
-      const int kb = rem / (CPB * 32);
+      const int n = (rem / CPB) % QROWS;
+      const int kb = rem / (CPB * QROWS);
       const int qi = min(q0 + x, p.nq - 1);
       int qlen = p.Lq;
       if (MODE == MODE_RERANK && p.q_len) qlen = min(qlen, p.q_len[qi]);
@@ -247,7 +259,7 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
         q[j] = (live && indim) ? load_q(p.Q, p.q_dtype, src + (indim ? j : 0)) : 0.0f;
         if (MODE == MODE_DENSE) q[j] *= qs;  // Q * q_mask[..., None], BaseModel.py:42
       }
-      char* dst = qlds + x * qimg + kb * SUB + n * BLKB + 16 * (c ^ (n & 15));
+      char* dst = qlds + x * qimg + kb * SUBQ + n * BLKB + 16 * (c ^ (n & 15));
       if constexpr (DT == MAXSIM_F32) {
         *(f32x4*)dst = f32x4{q[0], q[1], q[2], q[3]};
       } else {
@@ -269,14 +281,14 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
           u32x4 w;
 #pragma unroll
           for (int y = 0; y < 4; ++y) w[y] = (uint32_t)pc[k][2 * y] | ((uint32_t)pc[k][2 * y + 1] << 16);
-          *(u32x4*)(dst + k * KB * SUB) = w;
+          *(u32x4*)(dst + k * KB * SUBQ) = w;
         }
       }
     }
   }
   __syncthreads();  // the only workgroup barrier: the query images are read-only from here on
 
-  MultiReducer<QB, AM, SPLITK> red;
+  MultiReducer<QB, AM, SPLITK, HALFQ> red;
   red.init();
   int32_t* argq[QB];
 #pragma unroll
@@ -322,7 +334,8 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
 
 #pragma unroll
     for (int x = 0; x < QB; ++x) {
-      const char* qb = qlds + x * qimg + ckb * SUB + rdbase;  // query x, this block: same lane offsets as the doc image
+      // query x, this block: same lane offsets as the doc image (HALFQ: query columns 16..31 read columns 0..15 again)
+      const char* qb = qlds + x * qimg + ckb * SUBQ + (HALFQ ? rsw * BLKB : rdbase);
 #pragma unroll
       for (int i = 0; i < NRD; ++i) {
         const int qoff = 16 * ((2 * i + hh) ^ rsw);
@@ -335,12 +348,12 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream_bigh(KARGS_DECL) {
           const f16x8 av = __builtin_bit_cast(f16x8, a[i]);
           acc0[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + qoff), acc0[x], 0, 0, 0);
           if constexpr (NPQ == 2)
-            acc1[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + KB * SUB + qoff), acc1[x], 0, 0, 0);
+            acc1[x] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, *(const f16x8*)(qb + KB * SUBQ + qoff), acc1[x], 0, 0, 0);
         } else {
           const bf16x8 av = __builtin_bit_cast(bf16x8, a[i]);
           acc0[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + qoff), acc0[x], 0, 0, 0);
           if constexpr (NPQ == 2)
-            acc1[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + KB * SUB + qoff), acc1[x], 0, 0, 0);
+            acc1[x] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, *(const bf16x8*)(qb + KB * SUBQ + qoff), acc1[x], 0, 0, 0);
         }
       }
     }

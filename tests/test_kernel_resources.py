@@ -79,9 +79,9 @@ def test_headline_kernels_are_in_the_table(tables):
                      ("tu_stream", "k_maxsim_stream<0, 1, 4, 2, 0, 48, false, false, true>"),   # ragged fp16 index (token-balanced cut)
                      ("tu_stream", "k_maxsim_stream_uni<8, 1, 8, 0, false>"),                  # C4
                      ("tu_stream", "k_maxsim_stream_uni16<1, 8, 1, 8, 1, false>"),             # mv128
-                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 2, 1, 8, 2, false, 1, false, false, false, false>"),   # C5
-                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 1, 2, 8, 1, false, 1, false, false, false, true>"),    # dep768 (token-balanced cut)
-                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 1, 2, 8, 1, false, 1, false, false, false, false>"),   # mv768
+                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 2, 1, 4, 2, false, 1, false, false, false, false, false>"),   # C5
+                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 1, 2, 8, 1, false, 1, false, false, false, true, false>"),    # dep768 (token-balanced cut)
+                     ("tu_bigh_rerank", "k_maxsim_stream_bigh<0, 1, 2, 12, 1, false, 1, false, false, false, false, true>"),   # mv768 (16-row query image)
                      ("tu_allpairs", "k_maxsim_allpairs<2, 3, 3, true>")):                     # training forward
         assert name in want[tu], name
         assert want[tu][name]["scratch"] == 0

@@ -27,7 +27,7 @@ GUARDED = {
                   r"k_maxsim_stream<0, 0, 4, 1, 0, 16, false, (false|true), false>",
                   r"k_maxsim_stream<1, 0, 4, 1, 0, 32, false, false, false>", r"k_maxsim_stream_uni<[48], [12], (4|8|16), 0, (false|true)>",
                   r"k_maxsim_stream_uni16<.*>", r"k_maxsim_stream_f32h<.*>"],
-    "tu_bigh_rerank": [r"k_maxsim_stream_bigh<0, [012], [12], [48], [12], false, 1, false, false, false, (false|true)>", r"k_maxsim_bigh_uni<.*>"],
+    "tu_bigh_rerank": [r"k_maxsim_stream_bigh<0, [012], [12], (4|8|12), [12], false, 1, false, false, false, (false|true), (false|true)>", r"k_maxsim_bigh_uni<.*>"],
     "tu_allpairs": [r"k_maxsim_allpairs<[12], [123], [34], (false|true)>"],
 }
 
