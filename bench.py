@@ -96,9 +96,21 @@ def draw_candidates(n_docs, shape, gen, dev, lo=0):
     """Candidate pids drawn uniformly WITHOUT replacement within each list, `shape` = [..., ncand], in
     [lo, lo + n_docs): a uniform draw whose repeated entries (about ncand^2 / 2 n_docs per list) are re-drawn until none is left."""
     assert shape[-1] <= n_docs
+    ncand = shape[-1]
+    nrows = 1
+    for d in shape[:-1]:
+        nrows *= d
+    if 4 * ncand > n_docs:      # a large share of the range per list (tests, tiny indexes): the first ncand of a random permutation
+        flat = torch.empty(nrows, ncand, dtype=torch.int64, device=dev)
+        step = max(1, (1 << 24) // n_docs)
+        for a in range(0, nrows, step):
+            b = min(a + step, nrows)
+            flat[a:b] = torch.rand(b - a, n_docs, generator=gen, device=dev).argsort(dim=-1)[:, :ncand]
+        c = flat.view(shape)
+        return c + lo if lo else c
     c = torch.randint(0, n_docs, shape, generator=gen, device=dev, dtype=torch.int64)
-    flat = c.view(-1, shape[-1])
-    for _ in range(64):
+    flat = c.view(-1, ncand)
+    for _ in range(1000):       # (each pass re-draws the repeated entries: a handful after the first pass, none after two or three)
         srt, idx = flat.sort(dim=-1)
         dup = torch.zeros_like(srt, dtype=torch.bool)
         dup[:, 1:] = srt[:, 1:] == srt[:, :-1]
@@ -107,6 +119,8 @@ def draw_candidates(n_docs, shape, gen, dev, lo=0):
             break
         rows = dup.nonzero(as_tuple=True)
         flat[rows[0], idx[rows]] = torch.randint(0, n_docs, (n,), generator=gen, device=dev, dtype=torch.int64)
+    else:
+        raise RuntimeError("draw_candidates: repeated entries left after 1000 passes")
     return c + lo if lo else c
 
 
