@@ -7,10 +7,19 @@ namespace maxsim {
 namespace {
 
 // The ring shape launch_stream_bigh_q would pick for a rerank launch of this width / type (waves, sub-tiles per wave).
+// halfq: at most 16 query tokens on a 16-bit index of short docs (the multi-view configuration): the 16-row query image and 12
+// waves x 1 sub-tile, as the static grid (maxsim_launch_bigh.h; bit-identical scores)
 template <int DT, int NPQ>
-bool list_shape(const Params& p, int& waves, int& nt) {
+bool list_shape(const Params& p, int& waves, int& nt, bool& halfq) {
   constexpr int SUB = StreamTraits<DT>::TILE;
-  const int avail = 160 * 1024 - NPQ * ((p.h + 127) / 128) * SUB;
+  const int qfull = NPQ * ((p.h + 127) / 128) * SUB;
+  halfq = false;
+  if (DT != MAXSIM_F32 && p.Lq <= 16 && (p.h & 127) == 0 && p.n_docs > 0 && p.n_tokens <= 64 * p.n_docs &&
+      160 * 1024 - qfull / 2 >= 12 * SUB && MAXSIM_KNOB("MAXSIM_HALFQ", 1) != 0) {
+    halfq = true; waves = 12; nt = 1;
+    return true;
+  }
+  const int avail = 160 * 1024 - qfull;
   if (avail >= 8 * 2 * SUB) { waves = 8; nt = 2; return true; }
   if (NPQ == 2 && avail >= 8 * 1 * SUB) { waves = 8; nt = 1; return true; }
   if (avail >= 4 * 2 * SUB) { waves = 4; nt = 2; return true; }
@@ -22,11 +31,12 @@ template <int DT, int NPQ>
 int launch_list(Params& p, int64_t max_items, hipStream_t st) {
   constexpr int SUB = StreamTraits<DT>::TILE;
   int waves = 0, nt = 0;
-  if (!list_shape<DT, NPQ>(p, waves, nt)) return MAXSIM_ERANGE;
+  bool halfq = false;
+  if (!list_shape<DT, NPQ>(p, waves, nt, halfq)) return MAXSIM_ERANGE;
   const bool part = (p.h & 127) != 0;  // last block partial: the one ring shape the static grid uses for such widths
   if (part) { waves = 4; nt = 1; }
   const int KB = (p.h + 127) / 128;
-  const int ldsb = NPQ * KB * SUB + waves * nt * SUB;
+  const int ldsb = NPQ * KB * SUB / (halfq ? 2 : 1) + waves * nt * SUB;
   // one workgroup per CU is resident (the query image + rings take most of the LDS): a few rounds of them
   int64_t wgs = max_items < 1 ? 1 : max_items;
   const int cap = MAXSIM_KNOB("MAXSIM_LIST_WGS", 1024);
@@ -38,6 +48,9 @@ int launch_list(Params& p, int64_t max_items, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3((unsigned)wgs), dim3(waves * 64), ldsb, st, KARGS_PASS(p));
     return check_launch();
   };
+  if constexpr (DT != MAXSIM_F32) {
+    if (halfq) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 12, 1, false, 1, false, true, false, false, true>);
+  }
   if (part) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 4, 1, false, 1, true, true>);
   if (waves == 8 && nt == 2) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 8, 2, false, 1, false, true>);
   if (waves == 8) return go(k_maxsim_stream_bigh<MODE_RERANK, DT, NPQ, 8, 1, false, 1, false, true>);
@@ -53,11 +66,11 @@ int launch_list(Params& p, int64_t max_items, hipStream_t st) {
 int bigh_list_waves(const Params& p, int dt) {
   const bool same16 = dt != MAXSIM_F32 && p.q_dtype == dt;
   int waves = 0, nt = 0;
-  bool ok;
+  bool ok, halfq = false;
   switch (dt) {
-    case MAXSIM_F32: ok = list_shape<MAXSIM_F32, 1>(p, waves, nt); break;
-    case MAXSIM_F16: ok = same16 ? list_shape<MAXSIM_F16, 1>(p, waves, nt) : list_shape<MAXSIM_F16, 2>(p, waves, nt); break;
-    default: ok = same16 ? list_shape<MAXSIM_BF16, 1>(p, waves, nt) : list_shape<MAXSIM_BF16, 2>(p, waves, nt); break;
+    case MAXSIM_F32: ok = list_shape<MAXSIM_F32, 1>(p, waves, nt, halfq); break;
+    case MAXSIM_F16: ok = same16 ? list_shape<MAXSIM_F16, 1>(p, waves, nt, halfq) : list_shape<MAXSIM_F16, 2>(p, waves, nt, halfq); break;
+    default: ok = same16 ? list_shape<MAXSIM_BF16, 1>(p, waves, nt, halfq) : list_shape<MAXSIM_BF16, 2>(p, waves, nt, halfq); break;
   }
   return !ok ? 0 : (p.h & 127) ? 4 : waves;
 }
