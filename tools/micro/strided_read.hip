@@ -45,6 +45,67 @@ __global__ void __launch_bounds__(1024) k_strided(const char* __restrict__ buf, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+// The kernel's real cycle: a slot is READ (ds_read_b128 of the whole sub-tile into registers, s_waitcnt lgkmcnt(0)) before it is
+// re-issued.  NSLOT slots of SLOTB bytes per wave (8 KiB in all): 1 x 8 KiB (32 rows x 256 B: what the kernel has beside a 96 KiB
+// query image) against 2 x 4 KiB (32 rows x 128 B: a 64-dim sub-tile) -- with two slots one is always in flight.
+template <int NSLOT>
+__global__ void __launch_bounds__(1024) k_ring(const char* __restrict__ buf, int rowb, int tiles_per_wave, int ring_off, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  constexpr int SLOTB = 8192 / NSLOT, PIECE = SLOTB / 32, NI = SLOTB / 1024;   // 32 rows per sub-tile
+  constexpr int LPR = PIECE / 16, RPI = 64 / LPR;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int nwaves = blockDim.x >> 6;
+  char* const wlds = lds + ring_off + wave * 8192;
+  const int sweeps = rowb / PIECE;
+  const int64_t wid = (int64_t)blockIdx.x * nwaves + wave;
+  const char* const base = buf + wid * (int64_t)tiles_per_wave * 32 * rowb;
+  const uint32_t loff = (uint32_t)((lane / LPR) * rowb + (lane % LPR) * 16);
+  const int total = tiles_per_wave * sweeps;
+  auto issue = [&](int u, int slot) {
+    const char* const tile = base + (int64_t)(u / sweeps) * 32 * rowb + (u % sweeps) * PIECE;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+      __builtin_amdgcn_global_load_lds(GPTR(tile + (int64_t)(i * RPI) * rowb + loff), LPTR(wlds + slot * SLOTB + i * 1024), 16, 0, 2);
+  };
+  float acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < NSLOT; ++j) issue(j, j);
+  for (int u = 0; u < total; ++u) {
+    const int slot = u % NSLOT;
+    if (NSLOT == 2 && u + 1 < total) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NI) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 a[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a[i] = *(const f4*)(wlds + slot * SLOTB + i * 1024 + lane * 16);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (u + NSLOT < total) issue(u + NSLOT, slot);
+#pragma unroll
+    for (int i = 0; i < NI; ++i) acc += a[i][0];
+  }
+  if (acc == 123.456f) sink[0] = acc;
+}
+
+template <int NSLOT>
+double run_ring(const char* buf, size_t nbytes, int rowb, int waves, int ring_pad, float* sink) {
+  const int wgs = 256 * 8;
+  const size_t tile_bytes = (size_t)32 * rowb;
+  int tiles = (int)(nbytes / ((size_t)wgs * waves * tile_bytes));
+  if (tiles > 64) tiles = 64;
+  const size_t total = (size_t)wgs * waves * tiles * tile_bytes;
+  const int ldsb = ring_pad + waves * 8192;
+  (void)hipFuncSetAttribute((const void*)k_ring<NSLOT>, hipFuncAttributeMaxDynamicSharedMemorySize, ldsb);
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  hipLaunchKernelGGL(k_ring<NSLOT>, dim3(wgs), dim3(waves * 64), ldsb, 0, buf, rowb, tiles, ring_pad, sink);
+  (void)hipEventRecord(e0);
+  for (int r = 0; r < 3; ++r) hipLaunchKernelGGL(k_ring<NSLOT>, dim3(wgs), dim3(waves * 64), ldsb, 0, buf, rowb, tiles, ring_pad, sink);
+  (void)hipEventRecord(e1);
+  (void)hipEventSynchronize(e1);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, e0, e1);
+  return (double)total * 3 / (ms * 1e-3) / 1e9;
+}
+
 template <int PIECE>
 double run(const char* buf, size_t nbytes, int rowb, int waves, int ring_pad) {
   constexpr int RPS = 8192 / PIECE;
@@ -84,6 +145,14 @@ int main() {
       fflush(stdout);
     }
   }
-  hipFree(buf);
+  float* sink = nullptr;
+  (void)hipMalloc(&sink, 64);
+  for (int waves : {8, 12}) {
+    const int pad = 160 * 1024 - waves * 8192;
+    printf("rows of 1536 B, %d waves, slots READ before re-issue:  1 x 8 KiB (256-B pieces): %.0f GB/s   2 x 4 KiB (128-B pieces): %.0f GB/s\n",
+           waves, run_ring<1>(buf, nbytes, 1536, waves, pad, sink), run_ring<2>(buf, nbytes, 1536, waves, pad, sink));
+    fflush(stdout);
+  }
+  (void)hipFree(buf);
   return 0;
 }
