@@ -280,3 +280,47 @@ def test_sharded_output_D_embedding_on_gpu(ca, tmp_path):
         assert gp == ep and torch.equal(gD, eD) and torch.equal(gm, em)
     with pytest.raises(RuntimeError, match="Sizes of tensors must match"):
         sh.rank_forward(Q, z["pids"].tolist(), depth=6, output_D_embedding=True)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("L,Lq", [(16, 16), (16, 8), (8, 13), (16, 17), (4, 32)])
+def test_multiview_dim768_launch_forms_are_bit_identical(ca, dtype, L, Lq):
+    """Dim 768 (the reference's default, dense.yaml:8) with uniform short docs: the static grid (<= 16 query tokens: the 16-row
+    query image + 12 waves per workgroup), counted rows (the work-list form), one query per launch, the promise withdrawn,
+    fp32 and 16-bit queries, q_mask / q_len -- all return the same bits, and agree with the oracle's closed form."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(900 + L + Lq)
+    ndocs, h = 700, 768
+    emb = nrm(gen, ndocs * L, h).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[[L] * ndocs], dim=h, index_dtype=dtype)
+    g = without_promise(r)
+    for nq, ncand in ((1, 1), (3, 40), (2, 1000), (40, 130)):
+        Q = nrm(gen, nq, Lq, h)
+        cand = torch.randint(0, ndocs, (nq, ncand), generator=gen)
+        if ncand > 3:
+            cand[0, 1] = -1
+            cand[-1, ncand - 2] = ndocs + 3
+        qm = (torch.rand(nq, Lq, generator=gen) > 0.25).long()
+        qm[:, 0] = 1
+        ql = torch.randint(1, Lq + 1, (nq,), generator=gen)
+        counts = torch.randint(0, ncand + 1, (nq,), generator=gen)
+        counts[0] = ncand
+        cnt_rows = torch.full((nq, ncand), -1, dtype=torch.int64)
+        for q in range(nq):
+            cnt_rows[q, :int(counts[q])] = cand[q, :int(counts[q])].clamp(0, ndocs - 1)
+        for kw in (dict(), dict(q_mask=qm), dict(q_len=ql)):
+            for Qx in (Q, Q.to(dtype)):
+                a = r.score_candidates(Qx, cand.cuda(), **kw).cpu()
+                assert torch.equal(a, g.score_candidates(Qx, cand.cuda(), **kw).cpu()), (L, Lq, nq, ncand, list(kw), Qx.dtype)
+                for q in (0, nq - 1):                                  # one query per launch
+                    one_kw = {k: v[q:q + 1] for k, v in kw.items()}
+                    assert torch.equal(r.score_candidates(Qx[q:q + 1], cand[q:q + 1].cuda(), **one_kw).cpu()[0], a[q])
+                full = r.score_candidates(Qx, cnt_rows.cuda(), **kw).cpu()
+                counted = r.score_candidates(Qx, cnt_rows.cuda(), cand_count=counts.int().cuda(), **kw).cpu()
+                assert torch.equal(full, counted), (L, Lq, nq, ncand, list(kw), Qx.dtype)
+        a = r.score_candidates(Q, cand.cuda(), q_mask=qm).cpu()
+        if nq <= 3:
+            for qi in range(nq):
+                ok = [(c, p) for c, p in enumerate(cand[qi].tolist()) if 0 <= p < ndocs][:25]
+                exp = ragged_scores_f64(emb.float(), r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi][qm[qi].bool()], [p for _, p in ok])
+                np.testing.assert_allclose(a[qi, [c for c, _ in ok]].numpy(), exp, rtol=0, atol=ATOL16)
