@@ -755,6 +755,7 @@ def sharded_retrieve_step(sharded, ranker, Q, dev, world, doclens, steps=6, fais
 
 
 def main():
+    t_main = time.time()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -1080,6 +1081,7 @@ def main():
         if full:
             res["training_form"] = training_form_probe(dev)
             res["cpu_baseline"] = cpu_baseline()
+        res["wall_s"] = round(time.time() - t_main, 1)       # the whole run (index build, extra workloads, PMC children, CPU baseline)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(compact_line(res)) + "\n").encode())
     if use_dist:
@@ -1101,7 +1103,7 @@ def compact_line(res):
         details = f"not written: {type(e).__name__}"
     out = {k: res[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                "vs_baseline", "dtype", "data", "config") if k in res}
-    for k in ("n_ranks_seen", "backend", "per_rank", "sharded_self_check_ok", "stratified", "per_shard_1000"):
+    for k in ("wall_s", "n_ranks_seen", "backend", "per_rank", "sharded_self_check_ok", "stratified", "per_shard_1000"):
         if k in res:
             out[k] = res[k]
     if res.get("sharded_retrieve_step"):
