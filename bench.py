@@ -222,8 +222,8 @@ def live_pmc(budget_s=180.0):
     under `rocprofv3 --pmc` -- one counter set per pass, no trace domains, as MI355X_MICROARCH.md's HBM section prescribes:
       fetch  FETCH_SIZE over 1 warm-up + 3 rerank launches of the headline workload AND of every other_workloads entry
              (pmc_sweep_child); read bytes = 2 * FETCH_SIZE * 1024 (the guide's gfx950 correction for wide coalesced streams)
-      write  WRITE_SIZE, headline workload (1 + 3 launches): write bytes = WRITE_SIZE * 1024
-      sq     SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, headline workload
+      write  WRITE_SIZE, headline workload (12 warm-up + 3 counted launches): write bytes = WRITE_SIZE * 1024
+      sq     SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over GRBM_GUI_ACTIVE / 8 XCDs, headline workload (12 + 3 launches)
     Per-launch means over the 3 launches after the warm-up, from the passes' counter_collection.csv.
     Returns (fields, None) or (None, reason): the caller then replays profiles/."""
     import csv
@@ -246,7 +246,9 @@ def live_pmc(budget_s=180.0):
             if left < 20.0:
                 return None, f"time budget of {budget_s:.0f} s spent before the {name} pass"
             out = os.path.join(tmp, name)
-            child = ["--pmc-sweep"] if name == "fetch" else ["--steps", "3", "--warmup", "1", "--no-cpu-baseline"]
+            # (write / sq passes: 12 warm-up launches, so that the 3 counted ones run at the clock a loop of them holds, not on the ramp
+            # out of idle -- the first launches after a pause take 8.4, 5.1, 4.6, 4.4, 4.3 ms where the tenth takes 4.1)
+            child = ["--pmc-sweep"] if name == "fetch" else ["--steps", "3", "--warmup", "12", "--no-cpu-baseline"]
             cmd = [exe, "--pmc"] + counters + ["--output-format", "csv", "-d", out, "--", sys.executable, os.path.abspath(__file__)] + child
             try:
                 with open(os.path.join(tmp, name + ".log"), "w") as log:
@@ -273,11 +275,11 @@ def live_pmc(budget_s=180.0):
                 else:
                     if len(seq) < 2:
                         return None, f"{name} pass: no {c} rows for the rerank kernel"
-                    means[c] = sum(seq[1:]) / len(seq[1:])
+                    means[c] = sum(seq[-3:]) / len(seq[-3:])          # the 3 launches after the child's warm-ups
                     if c == "GRBM_GUI_ACTIVE":
                         # clock the chip held DURING those launches: cycles (summed over the 8 XCDs) / 8 / the same dispatches'
                         # own duration (MI355X_MICROARCH.md, DVFS give-back; a profiled pass runs a few % below an un-profiled one)
-                        rr = sorted((r for r in rows if r["Counter_Name"] == c), key=lambda r: int(r["Dispatch_Id"]))[1:]
+                        rr = sorted((r for r in rows if r["Counter_Name"] == c), key=lambda r: int(r["Dispatch_Id"]))[-3:]
                         try:
                             ghz = [float(r["Counter_Value"]) / 8.0 / (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rr]
                             means["effective_clock_GHz"] = sum(ghz) / len(ghz)
@@ -324,6 +326,29 @@ class PowerSampler:
                 if os.access(os.path.join(self.hw, f), os.R_OK):
                     self.pfile = os.path.join(self.hw, f)
                     break
+        # the firmware's own counters (tools/smi_sample.c, built by __graft_entry__.build(); absent -> skipped): one sample on
+        # either side of the region -> energy taken, share of the region with the package-power / thermal limiters active
+        self.smi, self.smi_dev, self.smi_a, self.smi_b = None, -1, None, None
+        try:
+            import ctypes
+            lib = ctypes.CDLL(os.path.join(ROOT, "tools", "libsmi_sample.so"))
+            lib.smi_open.argtypes, lib.smi_open.restype = [ctypes.c_uint32, ctypes.c_uint32], ctypes.c_int
+            lib.smi_read.argtypes, lib.smi_read.restype = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)], ctypes.c_int
+            pr = torch.cuda.get_device_properties(dev_index)
+            self.smi_dev = lib.smi_open(pr.pci_domain_id, pr.pci_bus_id)
+            if self.smi_dev >= 0:
+                self.smi = lib
+        except Exception:       # best effort by contract
+            self.smi = None
+
+    def _smi_read(self):
+        if self.smi is None:
+            return None
+        import ctypes
+        buf = (ctypes.c_double * 16)()
+        if self.smi.smi_read(self.smi_dev, buf) != 0:
+            return None
+        return time.perf_counter(), list(buf)
 
     @staticmethod
     def _rd(path):
@@ -340,6 +365,7 @@ class PowerSampler:
             self._stop.wait(self.period)
 
     def __enter__(self):
+        self.smi_a = self._smi_read()
         if self.pfile:
             import threading
             self._th = threading.Thread(target=self._loop, daemon=True)
@@ -347,20 +373,49 @@ class PowerSampler:
         return self
 
     def __exit__(self, *exc):
+        self.smi_b = self._smi_read()
         self._stop.set()
         if self._th is not None:
             self._th.join(timeout=1.0)
         return False
 
+    def _smi_summary(self):
+        """Differences of the firmware's counters over the region (None where the table does not carry a field)."""
+        if not self.smi_a or not self.smi_b:
+            return None
+        (ta, a), (tb, b) = self.smi_a, self.smi_b
+        out = {"interval_s": round(tb - ta, 4), "source": "SMI gpu_metrics table (tools/smi_sample.c), one sample before and one after the region"}
+        cyc = b[0] - a[0] if a[0] >= 0 and b[0] >= 0 else 0
+        out["accumulation_cycles"] = int(cyc)
+        if cyc > 0:
+            def share(i):
+                return None if a[i] < 0 or b[i] < 0 else round((b[i] - a[i]) / cyc, 4)
+            out["ppt_limiter_active_share"] = share(1)          # PVIOL: the package-power limiter held the clock down
+            th = [share(i) for i in (2, 3, 4, 5)]
+            out["thermal_limiters_active_share"] = None if all(x is None for x in th) else max(x for x in th if x is not None)
+        if a[6] >= 0 and b[6] >= 0 and b[11] > 0 and tb > ta:
+            out["energy_J"] = round((b[6] - a[6]) * b[11] * 1e-6, 2)
+            out["energy_avg_W"] = round(out["energy_J"] / (tb - ta), 1)
+        out["socket_power_W_after"] = None if b[7] < 0 else b[7]
+        out["sclk_target_MHz_after"] = None if b[8] < 0 else round(b[8])
+        out["hotspot_C_after"], out["mem_C_after"] = (None if b[9] < 0 else b[9]), (None if b[10] < 0 else b[10])
+        return out
+
     def summary(self):
         pw = [p for p, _ in self.samples if p is not None]
         fq = [f for _, f in self.samples if f is not None]
+        smi = self._smi_summary()
         if not pw:
-            return {"available": False}
+            return {"available": smi is not None, "firmware": smi} if smi else {"available": False}
         cap = self._rd(os.path.join(self.hw, "power1_cap"))
-        return {"available": True, "avg_W": round(sum(pw) / len(pw) / 1e6, 1), "max_W": round(max(pw) / 1e6, 1),
-                "cap_W": None if cap is None else round(cap / 1e6, 1), "sclk_MHz_avg": round(sum(fq) / len(fq) / 1e6) if fq else None,
-                "samples": len(pw), "source": "sysfs hwmon power1_input / freq1_input, sampled over the warm-up + timed steps"}
+        # (power1_input is the firmware's filtered average: over a region of ~0.1 s it is still climbing towards what a long
+        # loop of the same launches shows -- 1400 W after about a second; `firmware` below is exact over the region)
+        out = {"available": True, "avg_W": round(sum(pw) / len(pw) / 1e6, 1), "max_W": round(max(pw) / 1e6, 1),
+               "cap_W": None if cap is None else round(cap / 1e6, 1), "sclk_MHz_avg": round(sum(fq) / len(fq) / 1e6) if fq else None,
+               "samples": len(pw), "source": "sysfs hwmon power1_input (a filtered average) / freq1_input, sampled over the warm-up + timed steps"}
+        if smi:
+            out["firmware"] = smi
+        return out
 
 
 def timed_steps(step, warmup, steps, barrier=None):
@@ -368,15 +423,19 @@ def timed_steps(step, warmup, steps, barrier=None):
     issues step i and returns a handle (or None); a step's handle is resolved while the next step is in flight."""
     def finish(h):
         return h.result() if hasattr(h, "result") else h
-    for i in range(warmup):
-        finish(step(i))
     # the interpreter's cyclic garbage collector stays out of the timed region: a generation-2 pass walks the workloads'
     # million-element doclens lists (30-45 ms -- 4 ms per step of a 10-step region: the "host gap" of round 3's builder
-    # record, reproduced in round 4 as 4.6 vs 1.95 ms and 4.8 vs 0.23 ms between two regions of the same workload)
+    # record, reproduced in round 4 as 4.6 vs 1.95 ms and 4.8 vs 0.23 ms between two regions of the same workload).
+    # The collection runs BEFORE the warm-up steps, not between them and the timed ones: while the host collects, the GPU
+    # idles, its clocks fall within milliseconds, and the next ~8 launches climb back (round 5, kernel ms of consecutive C2
+    # steps: warm-up 8.4 5.1 4.6 4.4 4.3 | collect | timed 5.1 5.1 4.6 4.4 4.3 4.2 4.2 4.1 4.07 ... -- the warm-up undone,
+    # 4 % on a 20-step region); with nothing but the synchronize between them the timed steps continue where the warm-up ended
     gc_was_on = gc.isenabled()
     gc.collect()
     gc.disable()
     try:
+        for i in range(warmup):
+            finish(step(i))
         if barrier:
             barrier()
         torch.cuda.synchronize()
@@ -916,13 +975,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         kern_ms = sum(ev[i][0].elapsed_time(ev[i][1]) for i in range(args.warmup, total)) / args.steps
+        per_step_ms[:] = [round(ev[i][0].elapsed_time(ev[i][1]), 4) for i in range(total)][:130]
         xch = sharded.exchange_events or []
         xch_ms = sum(a.elapsed_time(b) for a, b in xch) / len(xch) if xch else 0.0
         return el, kern_ms, xch_ms
 
+    per_step_ms = []        # rerank kernel of every step, warm-ups first (side file only: does the region sit on a clock ramp?)
     with PowerSampler(dev.index if dev.index is not None else 0) as power:
         el, kern_ms, xch_ms = run(cands)
     power = power.summary()
+    headline_steps = list(per_step_ms)
 
     # algorithmic bytes of ONE rerank launch on this rank: doc tokens read once + Q + pid/offset/len + score
     cand_tokens, docs = live_tokens(ranker, cands, lo, hi, args.warmup, args.steps)
@@ -988,6 +1050,7 @@ def main():
         rf["pmc_launches_sampled"] = pmc_live["launches_sampled"]
     elif pmc_err is not None:
         rf["pmc_live_error"] = pmc_err
+    rf["kernel_ms_per_step"] = headline_steps
     rf["power"] = power        # board power / cap / sysfs shader clock over the headline's warm-up + timed steps (best effort)
 
     if rank == 0:
@@ -1148,6 +1211,7 @@ def compact_line(res):
     rf = dict(res["roofline"])
     if isinstance(rf.get("pmc_source"), str):
         rf["pmc_source"] = "live rocprofv3 --pmc child passes of this run" if rf["pmc_source"].startswith("live") else rf["pmc_source"]
+    rf.pop("kernel_ms_per_step", None)
     rc = rf.pop("read_ceiling", None)
     if rc:
         rf["read_ceiling_by_ring_shape"] = rc.get("by_ring_shape")
