@@ -948,7 +948,7 @@ def main():
     Q = Q.to(TDT[q_dtype])
     # candidate lists: GLOBAL pids, the same on every rank (same seed); a ring of NB distinct batches (one batch of docs
     # is >= 23 GB of tokens >> the 256 MB Infinity Cache, so re-using a batch NB steps later still reads HBM)
-    NB = total if job_world == 1 else min(total, 8)
+    NB = min(total, 64) if job_world == 1 else min(total, 8)      # (long profile loops: 64 batches = 1.5 TB of docs between re-uses)
     gen_c = torch.Generator(device=dev).manual_seed(2)
     cands = draw_candidates(job_world * ndocs, (NB, nq, ncand_q), gen_c, dev)
 

@@ -7,12 +7,18 @@ TAG=${1:-r04}
 NAMES=${2:-"c2_f32 c2_fp16 c2_f32bf16x3 c5_bf16 c4_f32 ragged_f32 dep768_fp16 c2_shard8_f32 single_query"}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
+# steps / warm-up per workload: ~0.5-1 s of GPU time in the traced run, the warm-ups covering the ~45 ms the clocks need to come
+# back from idle (tools/probe_step_timeline.py) -- the kernel-trace statistics average EVERY call, warm-ups included, so a run of
+# 3 + 20 launches (rounds 1-5a) reported the ramp: 4.17 ms for a kernel that holds 3.96-4.03
+SW() { case $1 in c4_f32|mv128_fp16) echo "3000 500";; mv768_fp16) echo "800 60";; c2_fp16|ragged_fp16) echo "400 30";; c5_bf16|dep768_fp16) echo "60 5";; *) echo "200 15";; esac; }
 prof() {  # name, bench args...
   local name=$1; shift
-  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${name}_trace -- python3 $R/bench.py "$@" --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_${name}_trace.log 2>&1 || return 1
-  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_${name}_fetch -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_${name}_fetch.log 2>&1 || return 1
-  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_${name}_write -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_${name}_write.log 2>&1 || return 1
-  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_${name}_sq -- python3 $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > $R/gpurun_out/${TAG}_${name}_sq.log 2>&1 || return 1
+  set -- "$@" --no-cpu-baseline
+  read S W <<< "$(SW $name)"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${name}_trace -- python3 $R/bench.py "$@" --steps $S --warmup $W > $R/gpurun_out/${TAG}_${name}_trace.log 2>&1 || return 1
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_${name}_fetch -- python3 $R/bench.py "$@" --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_${name}_fetch.log 2>&1 || return 1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_${name}_write -- python3 $R/bench.py "$@" --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_${name}_write.log 2>&1 || return 1
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_${name}_sq -- python3 $R/bench.py "$@" --steps 5 --warmup $(( W < 12 ? 12 : W )) > $R/gpurun_out/${TAG}_${name}_sq.log 2>&1 || return 1
   echo "profiled $name"
 }
 for n in $NAMES; do

@@ -4,7 +4,8 @@
     python tools/summarize_profile.py <tag> <trace_dir> [--fetch DIR] [--write DIR] [--sq DIR] [--kernels REGEX] [--skip N]
 
 --kernels: which kernels the per-launch PMC / steady-state summary covers (default: k_maxsim); --skip: warm-up launches
-dropped from the steady-state average (default 3).
+dropped from the steady-state average (default 3); --sq-skip: launches dropped from the front of the SQ pass's lists
+(default 0; tools/run_profiles.sh runs that pass with >= 12 warm-ups so that the counted launches are off the clock ramp).
 
 Writes profiles/<tag>_kernel_stats.csv (rocprofv3 --kernel-trace --stats summary, kernel names shortened),
 and profiles/<tag>_pmc.json (per-launch PMC values of the maxsim kernels).  HBM traffic follows
@@ -57,6 +58,7 @@ def main():
             if d:
                 steady[k] = {"launches": len(d), "avg_ns": sum(d) / len(d), "min_ns": min(d), "max_ns": max(d)}
     out = {}
+    sq_skip = int(opts.get("--sq-skip", 0))
     for key, flag in (("fetch", "--fetch"), ("write", "--write"), ("sq", "--sq")):
         d = opts.get(flag)
         if not d:
@@ -64,7 +66,12 @@ def main():
         cc = one(os.path.join(d, "**", "*counter_collection.csv"))
         if not cc:
             continue
-        for r in csv.DictReader(open(cc)):
+        rows_cc = sorted(csv.DictReader(open(cc)), key=lambda r: int(r["Dispatch_Id"]))
+        if key == "sq" and sq_skip:
+            ids = sorted({int(r["Dispatch_Id"]) for r in rows_cc if want.search(r["Kernel_Name"])})
+            drop = set(ids[:sq_skip])
+            rows_cc = [r for r in rows_cc if int(r["Dispatch_Id"]) not in drop]
+        for r in rows_cc:
             if not want.search(r["Kernel_Name"]):
                 continue
             k = short(r["Kernel_Name"]).split("(")[0]
