@@ -19,6 +19,13 @@ prof() {  # name, bench args...
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${TAG}_${name}_fetch -- python3 $R/bench.py "$@" --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_${name}_fetch.log 2>&1 || return 1
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${TAG}_${name}_write -- python3 $R/bench.py "$@" --steps 3 --warmup 1 > $R/gpurun_out/${TAG}_${name}_write.log 2>&1 || return 1
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${TAG}_${name}_sq -- python3 $R/bench.py "$@" --steps 5 --warmup $(( W < 12 ? 12 : W )) > $R/gpurun_out/${TAG}_${name}_sq.log 2>&1 || return 1
+  # keep what tools/summarize_profile.py reads (gpurun merges at most 64 MiB back)
+  find $R/gpurun_out/${TAG}_${name}_trace $R/gpurun_out/${TAG}_${name}_fetch $R/gpurun_out/${TAG}_${name}_write $R/gpurun_out/${TAG}_${name}_sq \
+       -type f ! -name '*kernel_stats.csv' ! -name '*kernel_trace.csv' ! -name '*counter_collection.csv' -delete 2>/dev/null
+  for f in $(find $R/gpurun_out/${TAG}_${name}_trace $R/gpurun_out/${TAG}_${name}_fetch $R/gpurun_out/${TAG}_${name}_write $R/gpurun_out/${TAG}_${name}_sq \
+             -type f \( -name '*kernel_trace.csv' -o -name '*counter_collection.csv' \)); do
+    grep -E "Kernel_Name|k_maxsim|k_topk" $f > $f.tmp; mv $f.tmp $f      # the library's kernels only (thousands of launches per traced run)
+  done
   echo "profiled $name"
 }
 for n in $NAMES; do
