@@ -1251,7 +1251,7 @@ def retrieve_step_probe(ranker, Q, dev, faiss_depth=512, hot=1500):
     """The batched driver's step after the ANN search (the reference: per query `emb2pid` + `set()` in a
     Pool(16), then rank_forward -- colbert_ranker.py:212-229, dense_server_client.py:44-48): 256 queries x (32 tokens x
     faiss_depth) synthetic ANN ids that cluster on ~1500 docs per query -> distinct pids (counted rows, nothing read
-    back) -> counted rerank -> counted top-100.  HIP events around each of the three launches' groups, 8 repetitions."""
+    back) -> counted rerank -> counted top-100.  HIP events around each of the three launches' groups, 8 repetitions after 60 ms of the same calls."""
     nq, nd = Q.size(0), ranker.n_docs
     n = Q.size(1) * faiss_depth
     g = torch.Generator(device=dev).manual_seed(7)
@@ -1259,16 +1259,8 @@ def retrieve_step_probe(ranker, Q, dev, faiss_depth=512, hot=1500):
     L = int(ranker.d_doclens[0].item())
     ids = docs.gather(1, torch.randint(0, hot, (nq, n), generator=g, device=dev)) * L + torch.randint(0, L, (nq, n), generator=g, device=dev)
 
-    def t(f, k=8):
-        for _ in range(2):
-            f()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(k):
-            f()
-        e1.record()
-        e1.synchronize()
-        return e0.elapsed_time(e1) / k
+    def t(f, k=8):      # (the batched step is a serving loop: timed on warm clocks, after 60 ms of the same calls)
+        return warm_then_time(f, k)
     ids = ids.view(nq, Q.size(1), faiss_depth)
     keep = torch.ones(nq, Q.size(1), dtype=torch.bool, device=dev)       # (the driver's keep-mask, applied in the kernels)
     cand, cnt = ranker.embedding_ids_to_pids(ids, trim=False, keep=keep)

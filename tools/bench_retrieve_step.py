@@ -36,16 +36,8 @@ ids = (docs.gather(1, torch.randint(0, hot, (NQ, n), generator=g, device=dev)) *
 keep = torch.rand(NQ, LQ, generator=g, device=dev) > 0.1
 
 
-def t(f, k=iters):
-    for _ in range(2):
-        f()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(k):
-        f()
-    e1.record()
-    e1.synchronize()
-    return round(e0.elapsed_time(e1) / k, 4)
+def t(f, k=iters):       # after 60 ms of the same calls: the clocks need ~45 ms of load to come back from idle
+    return round(bench.warm_then_time(f, k), 4)
 
 
 cand, cnt = r.embedding_ids_to_pids(ids, trim=False, keep=keep)

@@ -11,7 +11,7 @@ cd /tmp && export TMPDIR=/tmp
 for n in $NAMES; do
   case $n in
     retrieve) CMD="python3 $R/tools/bench_retrieve_step.py" ;;
-    train) CMD="python3 $R/tools/bench_training_form.py --iters 6 --no-torch" ;;
+    train) CMD="python3 $R/tools/bench_training_form.py --iters 60 --no-torch" ;;   # (60 iterations: ~0.25 s, off the clock ramp)
     *) echo "unknown $n"; exit 1 ;;
   esac
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${n}_trace -- $CMD > $R/gpurun_out/${TAG}_${n}_trace.log 2>&1 || exit 1
