@@ -305,7 +305,7 @@ class PowerSampler:
     {"available": False}.  It lets a reader of the bench line tell a slow BOX (power cap reached at a lower clock) from a
     regression.  sysfs clocks are context, not the test: roofline.effective_clock_GHz (PMC) is the in-kernel figure."""
 
-    def __init__(self, dev_index, period_s=0.004):
+    def __init__(self, dev_index, period_s=0.004, firmware=True):
         import glob
         import threading
         self.period, self.hw, self.samples, self._stop, self._th = period_s, None, [], threading.Event(), None
@@ -330,6 +330,8 @@ class PowerSampler:
         # either side of the region -> energy taken, share of the region with the package-power / thermal limiters active
         self.smi, self.smi_dev, self.smi_a, self.smi_b = None, -1, None, None
         try:
+            if not firmware:      # (N > 1: one process per GPU -- the SMI library's cross-process mutex stays out of a multi-rank run)
+                raise RuntimeError("firmware counters not requested")
             import ctypes
             lib = ctypes.CDLL(os.path.join(ROOT, "tools", "libsmi_sample.so"))
             lib.smi_open.argtypes, lib.smi_open.restype = [ctypes.c_uint32, ctypes.c_uint32], ctypes.c_int
@@ -1007,7 +1009,7 @@ def main():
         return el, kern_ms, xch_ms
 
     per_step_ms = []        # rerank kernel of every step, warm-ups first (side file only: does the region sit on a clock ramp?)
-    with PowerSampler(dev.index if dev.index is not None else 0) as power:
+    with PowerSampler(dev.index if dev.index is not None else 0, firmware=(world == 1)) as power:
         el, kern_ms, xch_ms = run(cands)
     power = power.summary()
     headline_steps = list(per_step_ms)
