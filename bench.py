@@ -337,7 +337,13 @@ class PowerSampler:
             lib.smi_open.argtypes, lib.smi_open.restype = [ctypes.c_uint32, ctypes.c_uint32], ctypes.c_int
             lib.smi_read.argtypes, lib.smi_read.restype = [ctypes.c_int, ctypes.POINTER(ctypes.c_double)], ctypes.c_int
             pr = torch.cuda.get_device_properties(dev_index)
-            self.smi_dev = lib.smi_open(pr.pci_domain_id, pr.pci_bus_id)
+            got = []
+            # (the library's start-up takes a cross-process lock: in a daemon thread with a deadline, so that a stale lock on
+            # the box costs this run its firmware sample, not its bench line)
+            th = threading.Thread(target=lambda: got.append(lib.smi_open(pr.pci_domain_id, pr.pci_bus_id)), daemon=True)
+            th.start()
+            th.join(timeout=8.0)
+            self.smi_dev = got[0] if got else -1
             if self.smi_dev >= 0:
                 self.smi = lib
         except Exception:       # best effort by contract
