@@ -248,7 +248,10 @@ def test_backward_with_skewed_argmax_buckets(ca, dtype, atol, nq):
 
 
 @pytest.mark.parametrize("h,dtype,lo,hi,gib", [(128, torch.float16, 40, 180, 4.6), (128, torch.float32, 8, 8, 4.4),
-                                               (768, torch.float16, 100, 300, 4.5), (128, torch.float32, 60, 180, 4.4)])
+                                               (768, torch.float16, 100, 300, 4.5), (128, torch.float32, 60, 180, 4.4),
+                                               # round 5's kernels: fixed-length 16-bit (k_maxsim_stream_uni16), and the 16-row query
+                                               # image + 12 waves of the LDS-query kernel (multi-view at dim 768)
+                                               (128, torch.float16, 8, 8, 4.3), (768, torch.float16, 16, 16, 4.3)])
 def test_candidates_beyond_4_gib_of_index(ca, h, dtype, lo, hi, gib):
     """Byte offsets past 2^32: an index of > 4 GiB per kernel family (h = 128 16-bit ragged, the fixed-length fp32 kernel,
     the LDS-query kernel at dim 768, h = 128 fp32 ragged), candidates drawn from its LAST docs, against the float64 closed form
@@ -269,7 +272,7 @@ def test_candidates_beyond_4_gib_of_index(ca, h, dtype, lo, hi, gib):
         idx[s:e] = F.normalize(torch.randn(e - s, h, generator=gd, device=dev), dim=-1).to(dtype)
     assert idx.numel() * esz > (1 << 32)
     r = ca.ColbertRanker.from_device_tensor(idx, doclens)
-    nq, ncand, Lq = 3, 40, 32 if lo > 8 else 8
+    nq, ncand, Lq = 3, 40, 32 if lo > 16 else lo
     Q = F.normalize(torch.randn(nq, Lq, h, generator=g), dim=-1)
     cand = torch.randint(ndocs - 400, ndocs, (nq, ncand), generator=g)                 # the tail of the index: offsets > 4 GiB
     assert int(r.doclens_pfxsum[ndocs - 400]) * h * esz > (1 << 32)
