@@ -324,3 +324,39 @@ def test_multiview_dim768_launch_forms_are_bit_identical(ca, dtype, L, Lq):
                 ok = [(c, p) for c, p in enumerate(cand[qi].tolist()) if 0 <= p < ndocs][:25]
                 exp = ragged_scores_f64(emb.float(), r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Q[qi][qm[qi].bool()], [p for _, p in ok])
                 np.testing.assert_allclose(a[qi, [c for c, _ in ok]].numpy(), exp, rtol=0, atol=ATOL16)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16], ids=["fp16", "bf16"])
+@pytest.mark.parametrize("Lq", [5, 16, 17])
+def test_short_queries_on_long_ragged_docs_at_dim768(ca, dtype, Lq):
+    """<= 16 query tokens at dim 768 on LONG ragged docs: the 16-row query image with the 8-wave rings (not the 12-wave shape of
+    the multi-view case), fp32 and 16-bit queries (two- and one-piece image), against the float64 closed form; static grid ==
+    counted rows == one query per launch; Lq = 17 is the 32-row image next to it."""
+    from oracle.maxsim_oracle import ragged_scores_f64
+    gen = torch.Generator().manual_seed(1700 + Lq)
+    ndocs, h = 300, 768
+    doclens = torch.randint(70, 330, (ndocs,), generator=gen).tolist()
+    doclens[5], doclens[6] = 1, 511
+    emb = nrm(gen, sum(doclens), h).to(dtype)
+    r = ca.ColbertRanker(parts=[emb], parts_doclens=[doclens], dim=h, index_dtype=dtype)
+    for nq, ncand in ((1, 7), (3, 60), (33, 140)):
+        Q = nrm(gen, nq, Lq, h)
+        cand = torch.randint(0, ndocs, (nq, ncand), generator=gen)
+        cand[0, :2] = torch.tensor([5, 6])
+        counts = torch.randint(1, ncand + 1, (nq,), generator=gen)
+        counts[0] = ncand
+        rows = torch.full((nq, ncand), -1, dtype=torch.int64)
+        for q in range(nq):
+            rows[q, :int(counts[q])] = cand[q, :int(counts[q])]
+        for Qx in (Q, Q.to(dtype)):
+            a = r.score_candidates(Qx, cand.cuda()).cpu()
+            assert torch.equal(r.score_candidates(Qx[:1], cand[:1].cuda()).cpu()[0], a[0])
+            full = r.score_candidates(Qx, rows.cuda()).cpu()
+            counted = r.score_candidates(Qx, rows.cuda(), cand_count=counts.int().cuda()).cpu()
+            assert torch.equal(full, counted), (Lq, nq, ncand, Qx.dtype)
+            live = rows >= 0
+            assert torch.equal(full[live], a[live])
+            for qi in range(min(nq, 2)):
+                pids = cand[qi].tolist()[:30]
+                exp = ragged_scores_f64(emb.float(), r.doclens, r.doclens_pfxsum, r.d_pad_len.cpu(), Qx[qi].float(), pids)
+                np.testing.assert_allclose(a[qi, :len(pids)].numpy(), exp, rtol=0, atol=ATOL16)
