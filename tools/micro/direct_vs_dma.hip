@@ -13,7 +13,13 @@
 #define LPTR(p) ((__attribute__((address_space(3))) void*)(p))
 typedef float f4 __attribute__((ext_vector_type(4)));
 
+// -DPRIO=1: the contraction at raised wave priority, as k_maxsim_stream runs it -- the matrix pipe then finishes one wave's tile
+// before the other wave's instead of interleaving them 1 : 1, so that one wave of a SIMD fetches while the other contracts
+#ifndef PRIO
+#define PRIO 0
+#endif
 __device__ __forceinline__ void block_mfma(const f4 (&d)[8], const float (&q)[2][32], f4 (&acc)[2]) {
+  if (PRIO) __builtin_amdgcn_s_setprio(3);
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -21,6 +27,7 @@ __device__ __forceinline__ void block_mfma(const f4 (&d)[8], const float (&q)[2]
       acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[i][e], q[0][4 * i + e], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(d[i][e], q[1][4 * i + e], acc[1], 0, 0, 0);
     }
+  if (PRIO) __builtin_amdgcn_s_setprio(0);
 }
 
 __device__ __forceinline__ float block_max(f4 (&acc)[2]) {
@@ -123,6 +130,49 @@ __global__ void __launch_bounds__(256, 2) k_direct(const char* __restrict__ buf,
   if (total == 123.456f) out[0] = total;
 }
 
+// (B2) as (B) with TWO whole tiles of registers in rotation (4 x 16-row blocks: one tile in flight while the other is contracted,
+// and the next requested block by block as its registers free up) -- 32 KiB per wave in flight at the peak, twice the LDS ring's
+template <bool MFMA>
+__global__ void __launch_bounds__(256, 2) k_direct2(const char* __restrict__ buf, const float* __restrict__ qsrc, int tiles_per_wave, float* out) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
+  const char* const base = buf + wid * (int64_t)tiles_per_wave * 16384 + (lane & 15) * 512 + (lane >> 4) * 16;
+  float q[2][32];
+  load_q(qsrc, lane, q);
+  const int nblk = tiles_per_wave * 2;
+  auto load = [&](f4 (&d)[8], int h) {
+    const f4* p = (const f4*)(base + (int64_t)(h < nblk ? h : nblk - 1) * 8192);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) d[i] = __builtin_nontemporal_load(p + 4 * i);
+  };
+  f4 acc[2] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+  float total = 0.f;
+  f4 A[8], B[8], C[8], D[8];
+  load(A, 0);
+  load(B, 1);
+  load(C, 2);
+  load(D, 3);
+  auto use = [&](f4 (&d)[8]) {
+    if (MFMA) {
+      block_mfma(d, q, acc);
+      total += block_max(acc);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) total += d[i][0] + d[i][3];
+    }
+  };
+#define STEP(X, k)                                \
+  if (h + k < nblk) use(X);                       \
+  __builtin_amdgcn_sched_barrier(0);              \
+  load(X, h + 4 + k);                             \
+  __builtin_amdgcn_sched_barrier(0);
+  for (int h = 0; h < nblk; h += 4) {
+    STEP(A, 0) STEP(B, 1) STEP(C, 2) STEP(D, 3)
+  }
+#undef STEP
+  if (total == 123.456f) out[0] = total;
+}
+
 // operands with live bits (zeros would cost the matrix pipe far less power than real embeddings do)
 __global__ void k_fill(float* p, size_t n) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -137,14 +187,14 @@ double run(K kern, int ldsb, const char* buf, const float* q, float* out, int wg
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
-  for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), ldsb, 0, buf, q, tiles, out);
+  for (int r = 0; r < 25; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), ldsb, 0, buf, q, tiles, out);   // ~100 ms: off the clock ramp
   (void)hipEventRecord(e0);
-  for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), ldsb, 0, buf, q, tiles, out);
+  for (int r = 0; r < 10; ++r) hipLaunchKernelGGL(kern, dim3(wgs), dim3(256), ldsb, 0, buf, q, tiles, out);
   (void)hipEventRecord(e1);
   (void)hipEventSynchronize(e1);
   float ms = 0;
   (void)hipEventElapsedTime(&ms, e0, e1);
-  return (double)wgs * 4 * tiles * 16384 * 5 / (ms * 1e-3) / 1e9;
+  return (double)wgs * 4 * tiles * 16384 * 10 / (ms * 1e-3) / 1e9;
 }
 
 int main() {
@@ -164,6 +214,9 @@ int main() {
     fflush(stdout);
     printf("direct to registers:      with MFMAs %.0f GB/s   fetch only %.0f GB/s\n", run(k_direct<true>, 0, buf, q, out, wgs, tiles),
            run(k_direct<false>, 0, buf, q, out, wgs, tiles));
+    fflush(stdout);
+    printf("direct, two tiles of registers: with MFMAs %.0f GB/s   fetch only %.0f GB/s\n", run(k_direct2<true>, 0, buf, q, out, wgs, tiles),
+           run(k_direct2<false>, 0, buf, q, out, wgs, tiles));
     fflush(stdout);
   }
   (void)hipFree(buf);
