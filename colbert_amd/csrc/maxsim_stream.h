@@ -841,12 +841,30 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
   int buf = 0;
 
   MAXSIM_STAMP_AT(2);  // first fetches issued, query in registers
+#ifdef MAXSIM_STAMP2  // (with MAXSIM_STAMP) per-wave sums over its tiles, 10 ns units: arrival wait | operand reads | next fetch issued | contraction + reduce
+  uint64_t ph_wait = 0, ph_read = 0, ph_issue = 0, ph_mm = 0;
+  // a time stamp the scheduler may not move anything across (the matrix instructions have no memory dependence to hold them)
+  auto ph_now = [&]() __attribute__((always_inline)) {
+    uint64_t t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+  };
+#endif
   while (nconsumed < nissued) {
     __builtin_amdgcn_s_setprio(0);
+#ifdef MAXSIM_STAMP2
+    const uint64_t ph_a = ph_now();
+#endif
     // tiles c+1 .. c+NT-1 were issued after this one iff the previous step issued
     if (prev_issued) wait_vmcnt<NDMA * (NT - 1)>(); else wait_vmcnt<0>();
 #ifdef MAXSIM_STAMP
     if (nconsumed == 0) stamp[3] = __builtin_amdgcn_s_memrealtime();  // the first tile has arrived
+#endif
+#ifdef MAXSIM_STAMP2
+    const uint64_t ph_b = ph_now();
+    ph_wait += ph_b - ph_a;
 #endif
     const char* tl = wlds + buf * TILE + rdbase;
     u32x4 a[NRD];
@@ -870,6 +888,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       }
     }
     wait_lgkmcnt0();  // operands are in registers: the buffer may be overwritten
+#ifdef MAXSIM_STAMP2
+    const uint64_t ph_c = ph_now();
+    ph_read += ph_c - ph_b;
+#endif
     {
       const TileMap t = fill_tile(F, dl, r);
       if (t.kind != 0) {
@@ -879,6 +901,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
       prev_issued = t.kind != 0;
     }
     buf = (buf + 1 == NT) ? 0 : buf + 1;
+#ifdef MAXSIM_STAMP2
+    const uint64_t ph_d = ph_now();
+    ph_issue += ph_d - ph_c;
+#endif
     // The contraction + reduce phase runs at raised priority: when both waves of a SIMD hold a tile, the matrix pipe
     // finishes one of them first (instead of interleaving both), so that wave's next fetch wait starts earlier.
     __builtin_amdgcn_s_setprio(3);
@@ -1121,6 +1147,9 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
 
     red.reduce_tile(sv, C, dl, lane);
     ++nconsumed;
+#ifdef MAXSIM_STAMP2
+    ph_mm += ph_now() - ph_d;
+#endif
   }
   MAXSIM_STAMP_AT(4);  // last tile contracted and reduced
   float* const srow = p.scores + (int64_t)qi * p.ncand + c_begin;
@@ -1130,6 +1159,10 @@ __global__ void __launch_bounds__(WAVES * 64) k_maxsim_stream(KARGS_DECL) {
     sb[0] = stamp[0]; sb[1] = stamp[1]; sb[2] = stamp[2]; sb[3] = stamp[3]; sb[4] = stamp[4];
     sb[5] = (uint64_t)nissued;
     sb[6] = __builtin_amdgcn_s_memrealtime();
+#ifdef MAXSIM_STAMP2
+    auto c16 = [](uint64_t v) { return v > 65535 ? (uint64_t)65535 : v; };
+    sb[7] = c16(ph_wait) | (c16(ph_read) << 16) | (c16(ph_issue) << 32) | (c16(ph_mm) << 48);
+#endif
   }
 #endif
   if constexpr (SPLITK) {

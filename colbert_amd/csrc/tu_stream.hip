@@ -188,6 +188,11 @@ int launch_stream(Params& p, hipStream_t st) {
     case 3: return launch_stream_v<MODE, DT, 4, NT0 * 2>(p, st); // deeper ring, 1 workgroup per CU
     default: break;
   }
+  if constexpr (MODE == MODE_RERANK && DT == MAXSIM_F32) {   // workgroups of 1 / 2 waves (a workgroup's slots are free only when its slowest wave ends)
+    const int wgw = MAXSIM_KNOB("MAXSIM_WG_WAVES", 4);
+    if (wgw == 1) return launch_stream_v<MODE, DT, 1, NT0>(p, st);
+    if (wgw == 2) return launch_stream_v<MODE, DT, 2, NT0>(p, st);
+  }
 #endif
   return launch_stream_v<MODE, DT, 4, NT0>(p, st);
 }
