@@ -177,6 +177,9 @@ int launch_stream(Params& p, hipStream_t st) {
     // higher sustained clock than 32x32x16 on the power cap; the fp16-split fast mode measured 1 % slower in this form
     // and keeps 32x32x16).  (diagnostic: MAXSIM_VARIANT=4 forces the 32x32x16 form)
 #ifdef MAXSIM_DIAG
+    if constexpr (DT == MAXSIM_F16) {   // five waves per workgroup: 2 x 80 KiB of rings fill the LDS, 10 waves per CU (3 + 3 + 2 + 2 per SIMD)
+      if (variant == 0 && MAXSIM_KNOB("MAXSIM_WG_WAVES", 4) == 5) return launch_stream_v<MODE, DT, 5, NT0, 0, QT_2X16>(p, st);
+    }
     if (variant == 0)
 #endif
       return launch_stream_v<MODE, DT, 4, NT0, 0, QT_2X16>(p, st);
