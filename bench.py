@@ -668,7 +668,8 @@ def extra_workload(colbert_amd, name, dev, steps, warmup, index_dtype=None, fp32
     shape = f"{lq}x{ld}" if wl["ragged"] is None else f"{lq}x~{wl['ragged'][0]} ({wl['ragged'][2]}..{wl['ragged'][3]} ragged)"
     out = {"workload": label or name, "shape": f"{NQ} queries x {NCAND} candidates, {shape} tokens, dim {h}, {index_dtype} index of "
                                                f"{len(doclens)} docs" + (f", fp32_mode {fp32_mode}" if fp32_mode != "exact" else ""),
-           "steps": steps, "warmup": warmup, "queries_per_s": round(NQ * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "steps": steps, "warmup": warmup, "prewarm_ms": PREWARM_MS,      # (untimed launches of step 0 in front of the warm-ups: timed_steps)
+           "queries_per_s": round(NQ * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
            "ms_per_step_both_regions": [round(r[0] / steps * 1e3, 4) for r in runs]}
     out.update({k: rf[k] for k in ("kernel", "kernel_ms", "algorithmic_bytes_per_launch", "achieved", "frac", "traffic",
                                    "pmc_source", "mfma_busy_frac", "mfma_tflops")})
